@@ -1,0 +1,156 @@
+/* vinterp.h - C-ABI of libvinterp.so, the MI355X (gfx950) implementation of the per-timestep
+ * fit + evaluate hot path of amisr/volumetricinterp.
+ *
+ * The reference is pure Python and has NO C/FFI boundary: its only plug-in seam is
+ * the Python `Model` class contract (volumetricinterp/models/sphharmlag.py:11-15).  This header is
+ * therefore the boundary *underneath* the reference's Python surface; each entry point cites the
+ * reference function whose arithmetic it replaces.  The binding a maintainer adds on the reference
+ * side is a ctypes stub - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (VI_OK) or a negative vi_status; nothing throws across the ABI;
+ *     vi_last_error() returns a thread-local message for the last failure.
+ *   - one vi_ctx per GPU, used from one host thread at a time.  All work is enqueued on the
+ *     context's own HIP stream; entry points taking device pointers are ASYNCHRONOUS on that
+ *     stream (call vi_ctx_sync), entry points taking host pointers stage H2D/D2H and return when
+ *     the result is in the caller's buffer.
+ *   - "d_" parameters are device pointers obtained from vi_dmalloc on the same context;
+ *     "h_" parameters are caller-owned, C-contiguous host buffers.  All reals are IEEE fp64.
+ *   - a failed timestep is reported through its outputs (NaN rows), never through the status.
+ */
+#ifndef VINTERP_H
+#define VINTERP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VI_ABI_VERSION 1
+
+typedef enum vi_status {
+    VI_OK = 0,
+    VI_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsupported order) */
+    VI_ERR_HIP = -2,         /* HIP runtime failure */
+    VI_ERR_ROCBLAS = -3,
+    VI_ERR_ROCSOLVER = -4,
+    VI_ERR_NOMEM = -5,
+    VI_ERR_UNSUPPORTED = -6,
+    VI_ERR_RCCL = -7
+} vi_status;
+
+typedef struct vi_ctx vi_ctx;       /* one per GPU: device id, stream, rocBLAS handle, workspaces */
+typedef struct vi_model vi_model;   /* device-resident tables of one basis model */
+
+enum { VI_MODEL_SPHHARMLAG = 1, VI_MODEL_RADBASFUN = 2 };
+
+/* One group of spherical-cap-harmonic degrees nu_l = nv_l + v0 that share the fractional part v0
+ * (sphharmlag.py:101-115 `nu`).  The Legendre functions P_nu^m(cos theta) of scipy.special.lpmv
+ * (called at sphharmlag.py:141) are produced by an upward degree recurrence seeded at degrees
+ * v0+m and v0+m+1, normalised so that one step is  p_j = x p_{j-1} - c[j][m] p_{j-2}. */
+typedef struct vi_sph_group {
+    double v0;               /* fractional part of the degrees of this group (0 -> closed-form seeds) */
+    int32_t nvmax;           /* largest integer part in the group */
+    int32_t nterms;          /* length of the 2F1 series tables (0 when v0 == 0) */
+    const int32_t* pick;     /* [nvmax+1]   l whose degree has integer part j, or -1 */
+    const double* c;         /* [(nvmax+1) x maxl]  normalised recurrence coefficient c[j][m] */
+    const double* seed_pref; /* [2 x maxl]  prefactor of the two seeds of chain m (v0 != 0) */
+    const double* seed_q;    /* [2 x maxl x nterms]  term ratios of the 2F1 series (v0 != 0) */
+} vi_sph_group;
+
+/* Model description (host side).  Built by volumetricinterp_amd.models.<NAME>.Model from the same
+ * INI keys the reference parses (sphharmlag.py:65-75, radbasfun.py:65-78). */
+typedef struct vi_model_desc {
+    int32_t kind;            /* VI_MODEL_* */
+    int32_t nbasis;          /* N = maxk*maxl^2 (sphharmlag.py:59) or NUMGRIDPNT^3 (radbasfun.py:60) */
+    /* --- sphharmlag --- */
+    int32_t maxk, maxl;
+    double rot_cos, rot_sin; /* cos/sin(theta0) of the Rodrigues rotation, sphharmlag.py:346,353 */
+    double rot_kx, rot_ky;   /* rotation axis k = (kx, ky, 0), sphharmlag.py:349 */
+    double earth_radius;     /* RE, sphharmlag.py:9 */
+    int32_t ngroups;
+    const vi_sph_group* groups;
+    const double* coef_scale;/* [maxl^2] per (l, signed m): Kvm(nu_l,|m|) (sphharmlag.py:305-321) x the
+                                lpmv negative-order factor x the chain normalisation */
+    /* --- radbasfun --- */
+    const double* centers;   /* [N x 3] ECEF metres (radbasfun.py:59) */
+    double eps;              /* radbasfun.py:72 */
+} vi_model_desc;
+
+/* ---- context / memory --------------------------------------------------------------------- */
+int  vi_abi_version(void);
+int  vi_device_count(int* count);
+int  vi_ctx_create(int device, vi_ctx** out);
+void vi_ctx_destroy(vi_ctx* ctx);
+int  vi_ctx_sync(vi_ctx* ctx);
+const char* vi_last_error(void);
+
+int  vi_dmalloc(vi_ctx* ctx, size_t bytes, void** d_ptr);
+int  vi_dfree(vi_ctx* ctx, void* d_ptr);
+int  vi_h2d(vi_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* synchronous */
+int  vi_d2h(vi_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
+int  vi_dmemset(vi_ctx* ctx, void* d_ptr, int value, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py measures kernels on the stream they run on) */
+int  vi_timer_start(vi_ctx* ctx);
+int  vi_timer_stop_ms(vi_ctx* ctx, double* ms);   /* synchronises on the stop event */
+
+/* ---- model -------------------------------------------------------------------------------- */
+int  vi_model_create(vi_ctx* ctx, const vi_model_desc* desc, vi_model** out);
+void vi_model_destroy(vi_model* model);
+
+/* ---- basis assembly: replaces Model.basis (sphharmlag.py:118-145, radbasfun.py:83-112) ------
+ * A[p*ld_p + n*ld_n] for p < P, n < N.  (ld_p, ld_n) = (N, 1) gives the reference's row-major
+ * (P, N) layout; (1, P) gives the N x P layout the fit kernels consume (coalesced stores). */
+int  vi_basis_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
+                  const double* d_alt, double* d_A, int64_t ld_p, int64_t ld_n);
+/* model coordinates (z, theta, phi) of sphharmlag.py:324-359 `transform_coord`; ECEF x,y,z for RBF */
+int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
+                      const double* d_alt, double* d_c0, double* d_c1, double* d_c2);
+
+/* ---- fused evaluation: replaces Estimate.__call__ (estimate.py:110-123) ---------------------
+ * out[t*Q + q] = sum_n basis_n(q) * C[t*N + n]; NaN where the point fails the convex-hull test
+ * (estimate.py:119-121, :153-178) when hull_eq != NULL: a point is inside iff
+ * max_f (hull_eq[f][0..2] . ecef(q) + hull_eq[f][3]) <= hull_tol.  The basis matrix is never
+ * materialised. */
+int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon,
+                 const double* d_alt, int64_t T, const double* d_C,
+                 const double* d_hull_eq, int32_t F, double hull_tol, double* d_out);
+/* host-pointer convenience form of the same call */
+int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const double* h_lon,
+                      const double* h_alt, int64_t T, const double* h_C,
+                      const double* h_hull_eq, int32_t F, double hull_tol, double* h_out);
+
+/* ---- fit: replaces Interpolate.eval_C (interpolate.py:432-469) -----------------------------
+ * Normal equations for T records sharing one basis matrix (records differ only in W and b;
+ * dropped points carry W = 0, b = 0 - algebraically the row removal of interpolate.py:516-520):
+ *   AWA[t] = A^T diag(W[t]) A  (interpolate.py:456),  y[t] = A^T (W[t] .* b[t])  (interpolate.py:458)
+ * d_At is the N x P basis (ld_n = P layout of vi_basis_f64). */
+int  vi_normal_eq_f64(vi_ctx* ctx, int64_t T, int64_t P, int32_t N, const double* d_At,
+                      const double* d_W, const double* d_b, double* d_AWA, double* d_y);
+
+/* X[i] = AWA[rec[i]] + alpha[i] * R   for a batch of B (record, alpha) pairs (interpolate.py:460-461) */
+int  vi_form_system_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
+                        const double* d_alpha, const double* d_R, double* d_X);
+
+/* Minimum-norm solve of the symmetric systems X[i] c = y[rec[i]] with singular values below
+ * rcond * sigma_max treated as zero - scipy.linalg.lstsq / LAPACK gelsd at interpolate.py:462
+ * (rcond = eps), via a batched symmetric eigendecomposition (sigma_i = |lambda_i|).
+ * d_X is destroyed.  Optionally also H = pinv(X) with its own cutoff (interpolate.py:465). */
+int  vi_solve_trunc_f64(vi_ctx* ctx, int64_t B, int32_t N, double* d_X, const double* d_y,
+                        const int32_t* d_rec, double rcond, double* d_C, int32_t* d_rank,
+                        double pinv_rcond, double* d_H /* may be NULL */);
+
+/* chi2[i] = sum_p W[rec[i]][p] (A[p,:] . C[i] - b[rec[i]][p])^2   (interpolate.py:258-259, :569) */
+int  vi_chi2_f64(vi_ctx* ctx, int64_t B, int64_t P, int32_t N, const double* d_At, const double* d_C,
+                 const int32_t* d_rec, const double* d_W, const double* d_b, double* d_chi2);
+
+/* dC[t] = H[t] AWA[t] H[t]   (interpolate.py:466) */
+int  vi_cov_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_H, const double* d_AWA, double* d_dC);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINTERP_H */

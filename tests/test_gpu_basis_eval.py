@@ -1,0 +1,176 @@
+"""GPU parity: HIP basis / transform / fused-evaluation kernels (through the C-ABI) against the golden
+vectors produced by the reference and against the CPU oracle on seeded inputs."""
+import datetime as dt
+import io
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, colnorm_err, rel
+
+pytestmark = pytest.mark.gpu
+
+CFG = """[DEFAULT]
+[MODEL]
+NAME = {name}
+MAXK = {k}
+MAXL = {l}
+CAP_LIM = {cap}
+MAX_Z_INT = INF
+LATCP = 78
+LONCP = 262
+EPS = 100000.0
+LATRANGE = 74,80
+LONRANGE = 260,285
+ALTRANGE = 100,600
+NUMGRIDPNT = {ngrid}
+"""
+
+SPH_VARIANTS = ['default', 'k8l2', 'k4l3', 'k3l4cap15', 'k2l5cap12p7', 'k2l3cap45', 'k8l12cap15', 'k2l12cap10']
+
+
+def sph_model(cfg):
+    from volumetricinterp_amd.models.sphharmlag import Model
+    return Model(io.StringIO(CFG.format(name='sphharmlag', k=int(cfg[0]), l=int(cfg[1]), cap=repr(float(cfg[2])), ngrid=7)))
+
+
+def rbf_model(ngrid=7):
+    from volumetricinterp_amd.models.radbasfun import Model
+    return Model(io.StringIO(CFG.format(name='radbasfun', k=4, l=6, cap=10, ngrid=ngrid)))
+
+
+@pytest.mark.parametrize('tag', SPH_VARIANTS)
+def test_transform_and_basis_vs_reference(tag):
+    g = load_golden('basis_sph')
+    m = sph_model(g[tag + '_cfg'])
+    lat, lon, alt = g[tag + '_lat'], g[tag + '_lon'], g[tag + '_alt']
+    z, t, p = m.transform_coord(lat, lon, alt)
+    np.testing.assert_allclose(z, g[tag + '_z'], rtol=0, atol=1e-11)       # gate L1 (z spans 0..11, 1e-12 rel)
+    np.testing.assert_allclose(t, g[tag + '_theta'], rtol=0, atol=1e-12)
+    # phi is undefined at the rotated pole (theta ~ 6e-5 rad for point 1): compare where sin(theta) is not tiny
+    ok = np.sin(g[tag + '_theta']) > 1e-3
+    np.testing.assert_allclose(p[ok], g[tag + '_phi'][ok], rtol=0, atol=1e-12)
+    A = m.basis(lat, lon, alt)
+    Aref = g[tag + '_A']
+    assert A.shape == Aref.shape
+    assert np.array_equal(np.isnan(A), np.isnan(Aref))
+    fin = np.isfinite(Aref).all(axis=0)
+    err = colnorm_err(A[:, fin], Aref[:, fin])
+    assert np.max(err) <= 1e-11, (tag, float(np.max(err)), int(np.argmax(err)))   # gate L2
+
+
+def test_basis_nd_and_layouts():
+    g = load_golden('basis_sph')
+    from volumetricinterp_amd import synth
+    m = sph_model(g['default_cfg'])
+    grid = synth.query_grid(3)
+    A = m.basis(*grid)
+    assert A.shape == (3, 3, 3, 144)
+    assert np.max(colnorm_err(A, g['nd_A'])) <= 1e-11
+    # N x P layout used by the fit kernels
+    ctx = m.ctx
+    P = grid[0].size
+    d = [ctx.to_device(a.ravel()) for a in grid]
+    At = m.basis_device(d[0], d[1], d[2], P, transposed=True).download()
+    assert np.array_equal(At.T, A.reshape(P, 144))
+    # empty input
+    assert m.basis(np.zeros((0,)), np.zeros((0,)), np.zeros((0,))).shape == (0, 144)
+
+
+def test_basis_vs_oracle_random_points():
+    import oracle
+    rng = np.random.default_rng(3)
+    n = 3000                                   # more than one 256-thread block, ragged tail
+    lat, lon, alt = rng.uniform(70, 86, n), rng.uniform(230, 290, n), rng.uniform(50e3, 900e3, n)
+    for cfg in ([4, 6, 10.], [3, 4, 15.]):
+        m = sph_model(cfg)
+        o = oracle.SphHarmLagOracle(maxk=cfg[0], maxl=cfg[1], cap_lim_deg=cfg[2])
+        A = m.basis(lat, lon, alt)
+        Aref = o.basis(lat, lon, alt)
+        assert np.max(colnorm_err(A, Aref)) <= 1e-11
+
+
+def test_rbf_basis_vs_reference():
+    g = load_golden('basis_rbf')
+    m = rbf_model()
+    np.testing.assert_allclose(m.centers, g['centers'], rtol=1e-15)
+    A = m.basis(g['lat'], g['lon'], g['alt'])
+    np.testing.assert_allclose(A, g['A'], rtol=2e-10, atol=1e-300)   # exp(-r^2/eps^2) with r^2/eps^2 up to ~1e3
+    assert np.max(colnorm_err(A, g['A'])) <= 1e-11
+    m3 = rbf_model(3)
+    assert np.max(colnorm_err(m3.basis(g['lat'], g['lon'], g['alt']), g['g3_A'])) <= 1e-11
+    from volumetricinterp_amd import synth
+    assert m.basis(*synth.query_grid(2)).shape == (2, 2, 2, 343)
+    R = m.transform_coords(g['lat'], g['lon'], g['alt'])
+    import oracle
+    np.testing.assert_allclose(R, np.array(oracle.geodetic2ecef(g['lat'], g['lon'], g['alt'])), rtol=1e-14)
+
+
+def _estimate(tag):
+    from volumetricinterp_amd.estimate import Estimate
+    f = load_golden('fit_' + tag)
+    return f, Estimate.from_arrays(f['Coeffs'], f['Covariance'], f['utime'], f['hull_vert'], str(f['cfg']))
+
+
+@pytest.mark.parametrize('tag', ['k8l2', 'default'])
+def test_estimate_vs_reference(tag):
+    e = load_golden('eval')
+    from volumetricinterp_amd import synth
+    f, es = _estimate(tag)
+    grid = synth.query_grid(6)
+    t_mid = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(e[tag + '_t_mid']))
+    out = es(t_mid, *grid, check_hull=False)
+    assert out.shape == (6, 6, 6)
+    assert rel(out, e[tag + '_nohull']) <= 1e-10                         # gate L6
+    outh = es(t_mid, *grid)                                              # check_hull=True is the default
+    assert np.array_equal(np.isnan(outh), np.isnan(e[tag + '_hull']))
+    ok = np.isfinite(outh)
+    assert rel(outh[ok], e[tag + '_hull'][ok]) <= 1e-10
+    assert np.array_equal(es.check_hull(*grid), np.isfinite(e[tag + '_hull']))
+    es.timeinterp = True
+    t_int = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(e[tag + '_t_int']))
+    assert rel(es(t_int, *grid, check_hull=False), e[tag + '_tinterp']) <= 1e-10
+    es.timeinterp = False
+    with pytest.raises(ValueError, match='Requested time out of range of data file.'):
+        es(t_mid - dt.timedelta(seconds=4000), *grid)
+    # calcgrad / calcerr are accepted and ignored
+    assert np.array_equal(es(t_mid, *grid, calcgrad=True, calcerr=True, check_hull=False), out)
+
+
+def test_eval_many_timesteps_and_ragged_sizes():
+    """T = 6 rows (one 4-tile + two single passes), Q not a multiple of the block size, vs the oracle."""
+    import oracle
+    f, es = _estimate('k8l2')
+    rng = np.random.default_rng(8)
+    Q = 777
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
+    C = np.concatenate([f['Coeffs'], f['Coeffs'][:2] * 0.5])            # (6, 32)
+    out = es.evaluate_coeffs(C, lat, lon, alt, check_hull=False)
+    o = oracle.SphHarmLagOracle(maxk=8, maxl=2)
+    A = o.basis(lat, lon, alt)
+    for t in range(6):
+        assert rel(out[t], A @ C[t]) <= 1e-10
+    # hull mask vs the reference's per-point Qhull on a subset
+    sub = slice(0, 120)
+    outh = es.evaluate_coeffs(C[:1], lat[sub], lon[sub], alt[sub], check_hull=True)
+    chk = oracle.check_hull(f['hull_vert'], lat[sub], lon[sub], alt[sub])
+    assert np.array_equal(np.isfinite(outh[0]), chk)
+    assert es.evaluate_coeffs(C, lat[:0], lon[:0], alt[:0]).shape == (6, 0)
+
+
+def test_rbf_estimate_vs_oracle():
+    import oracle
+    from volumetricinterp_amd.estimate import Estimate
+    f = load_golden('fit_rbf')
+    es = Estimate.from_arrays(f['Coeffs'], f['Covariance'], f['utime'], f['hull_vert'], str(f['cfg']))
+    rng = np.random.default_rng(9)
+    Q = 300
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(255, 270, Q), rng.uniform(100e3, 600e3, Q)
+    out = es.evaluate_coeffs(f['Coeffs'], lat, lon, alt, check_hull=False)
+    o = oracle.RadBasFunOracle.from_config(io.StringIO(str(f['cfg'])))
+    A = o.basis(lat, lon, alt)
+    for t in range(f['Coeffs'].shape[0]):
+        # |C| ~ 1e20 with heavy cancellation: compare against the size of the terms, not of the sum
+        scale = np.linalg.norm(np.abs(A) @ np.abs(f['Coeffs'][t]))
+        assert np.linalg.norm(out[t] - A @ f['Coeffs'][t]) <= 1e-11 * scale

@@ -1,0 +1,492 @@
+// Basis-function kernels for gfx950: geodetic -> model coordinates, Laguerre x spherical-cap
+// harmonics (reference: volumetricinterp/models/sphharmlag.py:118-145, :324-359) and Gaussian RBF
+// (reference: volumetricinterp/models/radbasfun.py:83-112), as
+//   K1  k_basis_*  : materialise A (used by the fit),
+//   K2  k_eval_*   : fused evaluation  out[t,q] = sum_n A[q,n] C[t,n]  (Estimate.__call__,
+//                    estimate.py:110-123) that never writes A, with the convex-hull test fused in.
+// One thread per point; lat/lon/alt are read as coalesced SoA streams; every table the 64 lanes of
+// a wave share (recurrence coefficients, coefficient tiles) is addressed wave-uniformly so it is
+// served by the scalar data path / LDS broadcast and never costs per-lane HBM traffic.
+#include "vi_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr double WGS84_A = 6378137.0;
+constexpr double WGS84_B = 6356752.31424518;
+constexpr double DEG2RAD = 0.017453292519943295;   // pi/180, the constant np.radians multiplies by
+
+struct Geom {
+    double X, Y, Z;          // ECEF, metres
+    double x, s;             // cos(theta), sin(theta) of the rotated colatitude
+    double cphi, sphi;       // cos/sin of the rotated azimuth
+    double z;                // 100 (r/RE - 1)
+    double Rx, Ry;           // rotated equatorial components (for atan2 in vi_transform)
+};
+
+// pymap3d.geodetic2ecef (WGS84 closed form), called at sphharmlag.py:351 / radbasfun.py:253
+__device__ __forceinline__ void geodetic2ecef(double lat, double lon, double alt, double& X, double& Y, double& Z)
+{
+    double sl, cl, so, co;
+    sincos(lat * DEG2RAD, &sl, &cl);
+    sincos(lon * DEG2RAD, &so, &co);
+    const double a2 = WGS84_A * WGS84_A, b2 = WGS84_B * WGS84_B;
+    const double Nn = a2 / sqrt(a2 * cl * cl + b2 * sl * sl);
+    const double ba = WGS84_B / WGS84_A;
+    X = (Nn + alt) * cl * co;
+    Y = (Nn + alt) * cl * so;
+    Z = (Nn * (ba * ba) + alt) * sl;
+}
+
+// sphharmlag.py:345-359: Rodrigues rotation about k = (kx, ky, 0) by +theta0 (sign as written, F3)
+__device__ __forceinline__ Geom sph_geom(const SphDev& M, double lat, double lon, double alt)
+{
+    Geom g;
+    geodetic2ecef(lat, lon, alt, g.X, g.Y, g.Z);
+    const double kd = M.kx * g.X + M.ky * g.Y;
+    const double omc = 1.0 - M.rc;
+    const double Rx = g.X * M.rc + (M.ky * g.Z) * M.rs + M.kx * kd * omc;
+    const double Ry = g.Y * M.rc + (-M.kx * g.Z) * M.rs + M.ky * kd * omc;
+    const double Rz = g.Z * M.rc + (M.kx * g.Y - M.ky * g.X) * M.rs;
+    const double rho2 = Rx * Rx + Ry * Ry;
+    const double r = sqrt(rho2 + Rz * Rz);
+    g.x = Rz / r;
+    g.s = sqrt(1.0 - g.x * g.x);          // scipy's lpmv forms (1-x^2)^(m/2) from x
+    const double rho = sqrt(rho2);
+    const bool pole = !(rho > 0.0);
+    g.cphi = pole ? 1.0 : Rx / rho;       // arctan2(0,0) = 0
+    g.sphi = pole ? 0.0 : Ry / rho;
+    g.z = 100.0 * (r / M.RE - 1.0);
+    g.Rx = Rx;
+    g.Ry = Ry;
+    return g;
+}
+
+// 2F1(a,b;c;zz) series with host-tabulated term ratios q[i] = (a+i)(b+i)/((c+i)(i+1)); the exit test
+// is wave-uniform so the table stays on the scalar path.
+__device__ __forceinline__ double hyp_series(const double* __restrict__ q, int nterms, double zz)
+{
+    double r = 1.0, sum = 1.0;
+    for (int i = 0; i < nterms; ++i) {
+        const double qi = q[i];
+        r *= qi * zz;
+        sum += r;
+        if (__all(fabs(r) <= 1e-17 * fabs(sum))) break;
+    }
+    return sum;
+}
+
+// The shared per-point engine.  Sink::consume(l, cur[], cm[], sm[]) is called once per degree l with
+// cur[m] = (normalised) P_{nu_l}^m(cos theta), m = 0..l.
+template <int LCAP, int KCAP, class Sink>
+__device__ __forceinline__ void sph_point(const SphDev& M, const Geom& g, Sink& sink)
+{
+    const int maxl = M.maxl;
+    // azimuthal factors cos(m phi), sin(m phi) by angle addition (sphharmlag.py:278-281 takes them of |m| phi)
+    double cm[LCAP], sm[LCAP];
+    cm[0] = 1.0;
+    sm[0] = 0.0;
+#pragma unroll
+    for (int m = 1; m < LCAP; ++m) {
+        cm[m] = cm[m - 1] * g.cphi - sm[m - 1] * g.sphi;
+        sm[m] = sm[m - 1] * g.cphi + cm[m - 1] * g.sphi;
+    }
+    const double x = g.x;
+    const double zz = 0.5 * (1.0 - x);
+    const int ng = M.ngroups;
+    for (int gi = 0; gi < ng; ++gi) {
+        const SphGroupDev G = M.groups[gi];
+        const bool intseed = (G.nterms == 0);
+        double cur[LCAP], prev[LCAP];
+#pragma unroll
+        for (int m = 0; m < LCAP; ++m) { cur[m] = 0.0; prev[m] = 0.0; }
+        double pmm = 1.0;       // (-1)^m (2m-1)!! s^m
+        double spow = 1.0;      // s^m
+        const int nvmax = G.nvmax;
+        for (int j = 0; j <= nvmax; ++j) {
+            const double* __restrict__ cj = G.c + (size_t)j * maxl;
+#pragma unroll
+            for (int m = 0; m < LCAP; ++m) {
+                if (m < maxl) {
+                    if (j > m + 1) {
+                        const double nw = fma(x, cur[m], -(cj[m] * prev[m]));
+                        prev[m] = cur[m];
+                        cur[m] = nw;
+                    } else if (j == m) {
+                        if (m > 0) { pmm *= -(2.0 * m - 1.0) * g.s; spow *= g.s; }
+                        if (intseed) cur[m] = pmm;
+                        else cur[m] = G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz);
+                    } else if (j == m + 1) {
+                        prev[m] = cur[m];
+                        if (intseed) cur[m] = x * (2.0 * m + 1.0) * cur[m];
+                        else cur[m] = G.pref[maxl + m] * spow *
+                                      hyp_series(G.q + (size_t)(maxl + m) * G.nterms, G.nterms, zz);
+                    }
+                }
+            }
+            const int l = G.pick[j];
+            if (l >= 0) sink.template consume<LCAP>(l, cur, cm, sm);
+        }
+    }
+}
+
+// scipy.special.eval_laguerre(k, z), k = 0..maxk-1, by the three-term recurrence (sphharmlag.py:141)
+template <int KCAP>
+__device__ __forceinline__ void laguerre(int maxk, double z, double* Lk)
+{
+    Lk[0] = 1.0;
+    if (KCAP > 1) Lk[1] = 1.0 - z;
+#pragma unroll
+    for (int k = 1; k + 1 < KCAP; ++k) {
+        const double inv = 1.0 / (double)(k + 1);
+        Lk[k + 1] = ((2.0 * k + 1.0 - z) * Lk[k] - (double)k * Lk[k - 1]) * inv;
+    }
+    (void)maxk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: basis assembly.  A[p*ld_p + n*ld_n], n = k*maxl^2 + l(l+1) + m  (sphharmlag.py:79-99)
+template <int KCAP>
+struct BasisSink {
+    double* A;
+    int64_t ld_n;
+    int maxk, L2;
+    const double* __restrict__ scale;
+    double ELk[KCAP];
+    bool active;
+    template <int LCAP>
+    __device__ __forceinline__ void consume(int l, const double* cur, const double* cm, const double* sm)
+    {
+        const int r0 = l * (l + 1);
+#pragma unroll
+        for (int m = 0; m < LCAP; ++m) {
+            if (m <= l) {
+                const double fp = scale[r0 + m] * cm[m] * cur[m];
+                const double fm = scale[r0 - m] * sm[m] * cur[m];
+#pragma unroll
+                for (int k = 0; k < KCAP; ++k) {
+                    if (k < maxk && active) {
+                        A[(int64_t)(k * L2 + r0 + m) * ld_n] = ELk[k] * fp;
+                        if (m > 0) A[(int64_t)(k * L2 + r0 - m) * ld_n] = ELk[k] * fm;
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int LCAP, int KCAP>
+__global__ __launch_bounds__(BLOCK) void k_basis_sph(SphDev M, int64_t P, const double* __restrict__ lat,
+                                                     const double* __restrict__ lon, const double* __restrict__ alt,
+                                                     double* __restrict__ A, int64_t ld_p, int64_t ld_n)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t pc = p < P ? p : P - 1;
+    const Geom g = sph_geom(M, lat[pc], lon[pc], alt[pc]);
+    BasisSink<KCAP> sink;
+    sink.A = A + pc * ld_p;
+    sink.ld_n = ld_n;
+    sink.maxk = M.maxk;
+    sink.L2 = M.maxl * M.maxl;
+    sink.scale = M.scale;
+    sink.active = p < P;
+    double Lk[KCAP];
+    laguerre<KCAP>(M.maxk, g.z, Lk);
+    const double E = exp(-0.5 * g.z);
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) sink.ELk[k] = E * Lk[k];
+    sph_point<LCAP, KCAP>(M, g, sink);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: fused evaluation for TT timesteps per pass.  Cp is the coefficient tile reordered to
+// [t][r = l(l+1)+m][k] and pre-multiplied by the per-(l,m) constant (see k_prep_coef).
+template <int KCAP, int TT>
+struct EvalSink {
+    const double* __restrict__ Cp;   // [TT][L2*maxk], wave-uniform reads
+    int maxk, NB;
+    double Lk[KCAP];
+    double acc[TT];
+    template <int LCAP>
+    __device__ __forceinline__ void consume(int l, const double* cur, const double* cm, const double* sm)
+    {
+        const int r0 = l * (l + 1);
+#pragma unroll
+        for (int m = 0; m < LCAP; ++m) {
+            if (m <= l) {
+                const double* __restrict__ cp = Cp + (size_t)(r0 + m) * maxk;
+                const double* __restrict__ cn = Cp + (size_t)(r0 - m) * maxk;
+                const double pc = cur[m] * cm[m];
+                const double ps = cur[m] * sm[m];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    double Sp = 0.0, Sm = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KCAP; ++k) {
+                        if (k < maxk) {
+                            Sp = fma(cp[(size_t)t * NB + k], Lk[k], Sp);
+                            if (m > 0) Sm = fma(cn[(size_t)t * NB + k], Lk[k], Sm);
+                        }
+                    }
+                    acc[t] = fma(pc, Sp, acc[t]);
+                    if (m > 0) acc[t] = fma(ps, Sm, acc[t]);
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ bool inside_hull(const double* __restrict__ eq, int F, double tol, double X, double Y, double Z)
+{
+    bool in = true;
+    for (int f = 0; f < F; ++f) {
+        const double d = fma(eq[4 * f], X, fma(eq[4 * f + 1], Y, fma(eq[4 * f + 2], Z, eq[4 * f + 3])));
+        in = in && (d <= tol);
+    }
+    return in;
+}
+
+template <int LCAP, int KCAP, int TT>
+__global__ __launch_bounds__(BLOCK) void k_eval_sph(SphDev M, int64_t Q, const double* __restrict__ lat,
+                                                    const double* __restrict__ lon, const double* __restrict__ alt,
+                                                    int tcount, const double* __restrict__ Cp,
+                                                    const double* __restrict__ hull, int F, double tol,
+                                                    double* __restrict__ out)
+{
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t qc = q < Q ? q : Q - 1;
+    const Geom g = sph_geom(M, lat[qc], lon[qc], alt[qc]);
+    bool in = true;
+    if (F > 0) {
+        in = inside_hull(hull, F, tol, g.X, g.Y, g.Z);
+        if (!__any(in && q < Q)) {            // whole wave outside the hull: skip the basis work
+            if (q < Q)
+                for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
+            return;
+        }
+    }
+    EvalSink<KCAP, TT> sink;
+    sink.Cp = Cp;
+    sink.maxk = M.maxk;
+    sink.NB = M.N;
+    laguerre<KCAP>(M.maxk, g.z, sink.Lk);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) sink.acc[t] = 0.0;
+    sph_point<LCAP, KCAP>(M, g, sink);
+    const double E = exp(-0.5 * g.z);
+    if (q < Q) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < tcount) out[(int64_t)t * Q + q] = in ? E * sink.acc[t] : __builtin_nan("");
+    }
+}
+
+// Cp[t][r*maxk + k] = C[t][k*L2 + r] * scale[r]
+__global__ void k_prep_coef(int T, int maxk, int L2, const double* __restrict__ C, const double* __restrict__ scale,
+                            double* __restrict__ Cp)
+{
+    const int N = maxk * L2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * N) return;
+    const int t = (int)(i / N), n = (int)(i % N);
+    const int r = n / maxk, k = n % maxk;
+    Cp[i] = C[(int64_t)t * N + k * L2 + r] * scale[r];
+}
+
+__global__ void k_transform_sph(SphDev M, int64_t P, const double* __restrict__ lat, const double* __restrict__ lon,
+                                const double* __restrict__ alt, double* z, double* th, double* ph)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Geom g = sph_geom(M, lat[p], lon[p], alt[p]);
+    z[p] = g.z;
+    th[p] = acos(g.x);
+    ph[p] = atan2(g.Ry, g.Rx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gaussian RBF model (radbasfun.py:83-112): A[p,n] = exp(-|R_p - c_n|^2 / eps^2), R in ECEF metres
+__global__ __launch_bounds__(BLOCK) void k_basis_rbf(RbfDev M, int64_t P, const double* __restrict__ lat,
+                                                     const double* __restrict__ lon, const double* __restrict__ alt,
+                                                     double* __restrict__ A, int64_t ld_p, int64_t ld_n)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= P) return;
+    double X, Y, Z;
+    geodetic2ecef(lat[p], lon[p], alt[p], X, Y, Z);
+    const double* __restrict__ c = M.centers;
+    for (int n = 0; n < M.N; ++n) {
+        const double dx = X - c[3 * n], dy = Y - c[3 * n + 1], dz = Z - c[3 * n + 2];
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        A[p * ld_p + (int64_t)n * ld_n] = exp(-r2 * M.inv_eps2);
+    }
+}
+
+template <int TT>
+__global__ __launch_bounds__(BLOCK) void k_eval_rbf(RbfDev M, int64_t Q, const double* __restrict__ lat,
+                                                    const double* __restrict__ lon, const double* __restrict__ alt,
+                                                    int tcount, const double* __restrict__ C,
+                                                    const double* __restrict__ hull, int F, double tol,
+                                                    double* __restrict__ out)
+{
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t qc = q < Q ? q : Q - 1;
+    double X, Y, Z;
+    geodetic2ecef(lat[qc], lon[qc], alt[qc], X, Y, Z);
+    bool in = true;
+    if (F > 0) {
+        in = inside_hull(hull, F, tol, X, Y, Z);
+        if (!__any(in && q < Q)) {
+            if (q < Q)
+                for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
+            return;
+        }
+    }
+    double acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = 0.0;
+    const double* __restrict__ c = M.centers;
+    for (int n = 0; n < M.N; ++n) {
+        const double dx = X - c[3 * n], dy = Y - c[3 * n + 1], dz = Z - c[3 * n + 2];
+        const double e = exp(-(dx * dx + dy * dy + dz * dz) * M.inv_eps2);
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < tcount) acc[t] = fma(e, C[(size_t)t * M.N + n], acc[t]);
+    }
+    if (q < Q) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < tcount) out[(int64_t)t * Q + q] = in ? acc[t] : __builtin_nan("");
+    }
+}
+
+__global__ void k_transform_rbf(int64_t P, const double* __restrict__ lat, const double* __restrict__ lon,
+                                const double* __restrict__ alt, double* X, double* Y, double* Z)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    geodetic2ecef(lat[p], lon[p], alt[p], X[p], Y[p], Z[p]);
+}
+
+inline unsigned nblocks(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+// (LCAP, KCAP) instantiations: default order; C5 order; larger orders
+template <int LCAP, int KCAP>
+int launch_basis_sph(vi_model* m, int64_t P, const double* lat, const double* lon, const double* alt, double* A,
+                     int64_t ld_p, int64_t ld_n)
+{
+    hipLaunchKernelGGL((k_basis_sph<LCAP, KCAP>), dim3(nblocks(P, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->sph, P,
+                       lat, lon, alt, A, ld_p, ld_n);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+template <int LCAP, int KCAP>
+int launch_eval_sph(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
+                    const double* Cp, const double* hull, int F, double tol, double* out)
+{
+    const int N = m->N;
+    int64_t t = 0;
+    while (t < T) {
+        const int64_t left = T - t;
+        if (left >= 4) {
+            hipLaunchKernelGGL((k_eval_sph<LCAP, KCAP, 4>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream,
+                               m->sph, Q, lat, lon, alt, 4, Cp + t * N, hull, F, tol, out + t * Q);
+            t += 4;
+        } else {
+            hipLaunchKernelGGL((k_eval_sph<LCAP, KCAP, 1>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream,
+                               m->sph, Q, lat, lon, alt, 1, Cp + t * N, hull, F, tol, out + t * Q);
+            t += 1;
+        }
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int vi_basis_f64(vi_model* m, int64_t P, const double* d_lat, const double* d_lon, const double* d_alt,
+                            double* d_A, int64_t ld_p, int64_t ld_n)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_A, "null argument");
+    VI_REQUIRE(P >= 0, "negative point count");
+    if (P == 0) return VI_OK;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    if (m->kind == VI_MODEL_SPHHARMLAG) {
+        const int L = m->sph.maxl, K = m->sph.maxk;
+        if (L <= 6 && K <= 4) return launch_basis_sph<6, 4>(m, P, d_lat, d_lon, d_alt, d_A, ld_p, ld_n);
+        if (L <= 12 && K <= 8) return launch_basis_sph<12, 8>(m, P, d_lat, d_lon, d_alt, d_A, ld_p, ld_n);
+        if (L <= 24 && K <= 16) return launch_basis_sph<24, 16>(m, P, d_lat, d_lon, d_alt, d_A, ld_p, ld_n);
+        vi_set_error("vi_basis_f64: order MAXL=%d MAXK=%d beyond the compiled limits (24, 16)", L, K);
+        return VI_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_basis_rbf, dim3(nblocks(P, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, P, d_lat, d_lon,
+                       d_alt, d_A, ld_p, ld_n);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+extern "C" int vi_transform_f64(vi_model* m, int64_t P, const double* d_lat, const double* d_lon, const double* d_alt,
+                                double* d_c0, double* d_c1, double* d_c2)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_c0 && d_c1 && d_c2, "null argument");
+    if (P <= 0) return P == 0 ? VI_OK : VI_ERR_INVALID;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    if (m->kind == VI_MODEL_SPHHARMLAG)
+        hipLaunchKernelGGL(k_transform_sph, dim3(nblocks(P, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->sph, P, d_lat,
+                           d_lon, d_alt, d_c0, d_c1, d_c2);
+    else
+        hipLaunchKernelGGL(k_transform_rbf, dim3(nblocks(P, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, P, d_lat, d_lon,
+                           d_alt, d_c0, d_c1, d_c2);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                           int64_t T, const double* d_C, const double* d_hull_eq, int32_t F, double hull_tol,
+                           double* d_out)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_C && d_out, "null argument");
+    VI_REQUIRE(Q >= 0 && T >= 0 && F >= 0, "negative size");
+    VI_REQUIRE(F == 0 || d_hull_eq, "hull facet count given without facet equations");
+    if (Q == 0 || T == 0) return VI_OK;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    const int N = m->N;
+    if (m->kind == VI_MODEL_SPHHARMLAG) {
+        const size_t need = (size_t)T * N * sizeof(double);
+        if (need > m->coef_bytes) {
+            if (m->d_coef) VI_HIP(hipFree(m->d_coef));
+            m->d_coef = nullptr;
+            m->coef_bytes = 0;
+            VI_HIP(hipMalloc((void**)&m->d_coef, need));
+            m->coef_bytes = need;
+        }
+        const int L2 = m->sph.maxl * m->sph.maxl;
+        hipLaunchKernelGGL(k_prep_coef, dim3(nblocks((int64_t)T * N, 256)), dim3(256), 0, m->ctx->stream, (int)T,
+                           m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
+        VI_HIP(hipGetLastError());
+        const int L = m->sph.maxl, K = m->sph.maxk;
+        if (L <= 6 && K <= 4)
+            return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+        if (L <= 12 && K <= 8)
+            return launch_eval_sph<12, 8>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+        if (L <= 24 && K <= 16)
+            return launch_eval_sph<24, 16>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+        vi_set_error("vi_eval_f64: order MAXL=%d MAXK=%d beyond the compiled limits (24, 16)", L, K);
+        return VI_ERR_UNSUPPORTED;
+    }
+    int64_t t = 0;
+    while (t < T) {
+        const int tc = (int)((T - t) >= 4 ? 4 : (T - t));
+        if (tc == 4)
+            hipLaunchKernelGGL(k_eval_rbf<4>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
+                               d_lon, d_alt, tc, d_C + t * N, d_hull_eq, F, hull_tol, d_out + t * Q);
+        else
+            hipLaunchKernelGGL(k_eval_rbf<1>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
+                               d_lon, d_alt, 1, d_C + t * N, d_hull_eq, F, hull_tol, d_out + t * Q);
+        VI_HIP(hipGetLastError());
+        t += (tc == 4) ? 4 : 1;
+    }
+    return VI_OK;
+}

@@ -1,0 +1,87 @@
+// Internal definitions shared by the translation units of libvinterp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vinterp.h"
+
+void vi_set_error(const char* fmt, ...);
+
+#define VI_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            vi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return VI_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define VI_ROCBLAS(call)                                                                      \
+    do {                                                                                      \
+        rocblas_status s_ = (call);                                                           \
+        if (s_ != rocblas_status_success) {                                                   \
+            vi_set_error("%s:%d: %s -> rocblas status %d", __FILE__, __LINE__, #call, (int)s_); \
+            return VI_ERR_ROCBLAS;                                                            \
+        }                                                                                     \
+    } while (0)
+
+#define VI_REQUIRE(cond, msg)                                  \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            vi_set_error("%s: %s", __func__, msg);             \
+            return VI_ERR_INVALID;                             \
+        }                                                      \
+    } while (0)
+
+struct vi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // grow-only device workspace for the fit entry points
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    int n_cu = 256;
+};
+
+int vi_ctx_workspace(vi_ctx* ctx, size_t bytes, void** out);
+
+// ---- device-side model tables ----------------------------------------------------------------
+struct SphGroupDev {
+    double v0;
+    int nvmax;
+    int nterms;
+    const int* pick;        // [nvmax+1]
+    const double* c;        // [(nvmax+1) x maxl]
+    const double* pref;     // [2 x maxl]
+    const double* q;        // [2 x maxl x nterms]
+};
+
+struct SphDev {
+    int maxk, maxl, N, ngroups;
+    double rc, rs, kx, ky, RE;
+    const SphGroupDev* groups;
+    const double* scale;    // [maxl^2]
+};
+
+struct RbfDev {
+    int N;
+    double inv_eps2;
+    const double* centers;  // [N x 3]
+};
+
+struct vi_model {
+    vi_ctx* ctx = nullptr;
+    int kind = 0;
+    int N = 0;
+    SphDev sph{};
+    RbfDev rbf{};
+    std::vector<void*> allocs;   // device allocations owned by the model
+    double* d_coef = nullptr;    // reordered + scaled coefficient staging for vi_eval (grow-only)
+    size_t coef_bytes = 0;
+};

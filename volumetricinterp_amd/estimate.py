@@ -1,0 +1,140 @@
+"""Evaluate a fitted model at arbitrary geodetic points on the MI355X.
+
+Drop-in mirror of the reference class ``volumetricinterp/estimate.py:13-221``:
+same constructor, same ``__call__`` signature and error behaviour, same
+``get_C`` time selection.  ``__call__`` runs the fused HIP kernel
+(``vi_eval_f64``: coordinates -> basis -> contraction with C -> hull mask)
+instead of materialising ``A`` (1 152 B per point at N = 144) and calling
+``einsum`` (estimate.py:113-115); the per-point Qhull of ``check_hull``
+(estimate.py:153-178) becomes one host Qhull plus a half-space test fused in
+the kernel.
+"""
+import configparser
+import datetime as dt
+import importlib
+import io
+
+import numpy as np
+from scipy.spatial import ConvexHull
+
+from . import _lib
+
+
+def hull_equations(hull_vert):
+    """Facet half-spaces (F, 4) of the data hull: inside <=> eq[:, :3] @ x + eq[:, 3] <= tol."""
+    hull_vert = np.ascontiguousarray(hull_vert, dtype=np.float64)
+    eq = np.ascontiguousarray(ConvexHull(hull_vert).equations, dtype=np.float64)
+    # Qhull treats a point within its distance round-off of a facet as coplanar (not a new vertex),
+    # which the reference's vertex-list comparison (estimate.py:174-176) then reports as inside.
+    tol = 4. * np.finfo(np.float64).eps * 3. * float(np.max(np.abs(hull_vert)))
+    return eq, tol
+
+
+class Estimate(object):
+    def __init__(self, coeff_filename, timetol=60., timeinterp=False, ctx=None):
+        self.timetol = timetol
+        self.timeinterp = timeinterp
+        self._ctx = ctx
+        self.loadh5(filename=coeff_filename)
+        self._init_model()
+
+    @classmethod
+    def from_arrays(cls, Coeffs, Covariance, time, hull_vert, config_text, timetol=60., timeinterp=False, ctx=None):
+        """Build an Estimate from in-memory fit results (what loadh5 would have read)."""
+        self = cls.__new__(cls)
+        self.timetol, self.timeinterp, self._ctx = timetol, timeinterp, ctx
+        self.Coeffs = np.asarray(Coeffs, dtype=np.float64)
+        self.Covariance = None if Covariance is None else np.asarray(Covariance, dtype=np.float64)
+        self.time = np.asarray(time)
+        self.hull_vert = np.asarray(hull_vert, dtype=np.float64)
+        self.config_file_text = config_text.encode('utf-8') if isinstance(config_text, str) else config_text
+        self._init_model()
+        return self
+
+    def _init_model(self):
+        # estimate.py:41-50: the model is rebuilt from the config text embedded in the file
+        config_file = io.StringIO(self.config_file_text.decode('utf-8'))
+        config = configparser.ConfigParser()
+        config.read_file(config_file)
+        self.model_name = config.get('MODEL', 'NAME')
+        config_file.seek(0)
+        m = importlib.import_module('.models.' + self.model_name, package='volumetricinterp_amd')
+        self.model = m.Model(config_file, ctx=self._ctx)
+        self._hull_eq = None
+
+    # estimate.py:53-70
+    def loadh5(self, filename=None):
+        from .h5io import read_coeff_file
+        d = read_coeff_file(filename)
+        self.Coeffs = d['Coeffs']
+        self.Covariance = d['Covariance']
+        self.time = d['time']
+        self.hull_vert = d['hull_vert']
+        self.config_file_text = d['config_file_text']
+
+    def _hull(self):
+        if self._hull_eq is None:
+            self._hull_eq = hull_equations(self.hull_vert)
+        return self._hull_eq
+
+    # estimate.py:75-123
+    def __call__(self, time, gdlat, gdlon, gdalt, calcgrad=False, calcerr=False, check_hull=True):
+        # calcgrad / calcerr are accepted and ignored, exactly as in the reference (code after the
+        # `return` at estimate.py:123 is dead)
+        C, dC = self.get_C(time)
+        gdlat = np.asarray(gdlat, dtype=np.float64)
+        out = self.evaluate_coeffs(np.asarray(C, dtype=np.float64)[None, :], gdlat, gdlon, gdalt, check_hull)
+        return out[0].reshape(gdlat.shape)
+
+    def evaluate_coeffs(self, C, gdlat, gdlon, gdalt, check_hull=True):
+        """out[t] = density of coefficient row C[t] at the points; (T, Q)."""
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        lat = np.ascontiguousarray(np.asarray(gdlat, dtype=np.float64).ravel())
+        lon = np.ascontiguousarray(np.asarray(gdlon, dtype=np.float64).ravel())
+        alt = np.ascontiguousarray(np.asarray(gdalt, dtype=np.float64).ravel())
+        if not (lat.size == lon.size == alt.size):
+            raise ValueError('gdlat, gdlon, gdalt must have the same shape')
+        T, Q = C.shape[0], lat.size
+        if C.shape[1] != self.model.nbasis:
+            raise ValueError('coefficient vector length %d != nbasis %d' % (C.shape[1], self.model.nbasis))
+        out = np.empty((T, Q), dtype=np.float64)
+        if Q == 0 or T == 0:
+            return out
+        h = self.model.handle()
+        P = _lib.c_double_p
+        if check_hull:
+            eq, tol = self._hull()
+            F, eqp = eq.shape[0], eq.ctypes.data_as(P)
+        else:
+            tol, F, eqp = 0., 0, None
+        _lib.check(_lib.lib.vi_eval_f64_host(h, Q, lat.ctypes.data_as(P), lon.ctypes.data_as(P),
+                                             alt.ctypes.data_as(P), T, C.ctypes.data_as(P), eqp, F, tol,
+                                             out.ctypes.data_as(P)), 'vi_eval_f64_host')
+        return out
+
+    # estimate.py:153-178 (boolean mask, same shape as the inputs)
+    def check_hull(self, lat0, lon0, alt0):
+        alt0 = np.asarray(alt0, dtype=np.float64)
+        z = np.zeros((1, self.model.nbasis))
+        out = self.evaluate_coeffs(z, lat0, lon0, alt0, check_hull=True)
+        return np.isfinite(out[0]).reshape(alt0.shape)
+
+    # estimate.py:180-221
+    def get_C(self, t):
+        t0 = (t - dt.datetime(1970, 1, 1)).total_seconds()
+        mt = np.mean(self.time, axis=1)
+        try:
+            if self.timeinterp:
+                i = np.argwhere((t0 >= mt[:-1]) & (t0 < mt[1:])).flatten()[0]
+                T = (t0 - mt[i]) / (mt[i + 1] - mt[i])
+                C = (1 - T) * self.Coeffs[i, :] + T * self.Coeffs[i + 1, :]
+                dC = (1 - T) * self.Covariance[i, :, :] + T * self.Covariance[i + 1, :, :]
+            else:
+                i = np.argmin(np.abs(mt - t0))
+                if np.abs(mt[i] - t0) > self.timetol:
+                    raise IndexError
+                C = self.Coeffs[i]
+                dC = self.Covariance[i]
+        except IndexError:
+            raise ValueError('Requested time out of range of data file.')
+        return C, dC
