@@ -131,7 +131,8 @@ int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const dou
 int  vi_normal_eq_f64(vi_ctx* ctx, int64_t T, int64_t P, int32_t N, const double* d_At,
                       const double* d_W, const double* d_b, double* d_AWA, double* d_y);
 
-/* X[i] = AWA[rec[i]] + alpha[i] * R   for a batch of B (record, alpha) pairs (interpolate.py:460-461) */
+/* X[i] = AWA[rec[i]] + alpha[i] * R   for a batch of B (record, alpha) pairs (interpolate.py:460-461);
+ * d_rec == NULL means rec[i] = i; d_AWA == NULL accumulates a further penalty term, X[i] += alpha[i] * R. */
 int  vi_form_system_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                         const double* d_alpha, const double* d_R, double* d_X);
 

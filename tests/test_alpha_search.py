@@ -1,0 +1,130 @@
+"""Host-side scalar logic of the regularisation-parameter search (gate L5) and the brentq restatement."""
+import math
+
+import numpy as np
+import pytest
+import scipy.optimize
+
+from conftest import load_golden
+from volumetricinterp_amd import alpha_search as AS
+
+
+def drive(gen_fn, f):
+    """Run a coroutine against a plain function; returns (result, list of x requested)."""
+    g = gen_fn
+    xs = []
+    try:
+        x = next(g)
+        while True:
+            xs.append(x)
+            x = g.send(f(x))
+    except StopIteration as stop:
+        return stop.value, xs
+
+
+FUNCS = [
+    (lambda x: x**3 - 2 * x - 5, 2., 3.),
+    (lambda x: math.cos(x) - x, 0., 1.),
+    (lambda x: math.exp(-x) - 1e-3 * x**2 - 0.5, -1., 4.),
+    (lambda x: (x - 0.3) * (1 + 50 * (x - 0.3)**2), -1., 1.),          # odd, steep
+    (lambda x: math.tanh(40 * (x + 20.37)) * 500 + 3, -21., -20.),     # step-like, as chi2-nu can be
+    (lambda x: 1e-9 * (x + 30.5), -31., -30.),
+    (lambda x: x, -1., 0.),                                             # root at the bracket end
+]
+
+
+@pytest.mark.parametrize('case', range(len(FUNCS)))
+def test_brentq_restatement_matches_scipy_call_for_call(case):
+    f, a, b = FUNCS[case]
+    calls = []
+
+    def logged(x):
+        calls.append(x)
+        return f(x)
+    ref, info = scipy.optimize.brentq(logged, a, b, full_output=True, disp=True)
+    (root, iters, funcalls), xs = drive(AS.brentq_gen(a, b), f)
+    assert root == ref                      # bit-identical iterate sequence
+    assert xs == calls
+    assert funcalls == info.function_calls
+    if info.function_calls > 2:             # SciPy leaves `iterations` uninitialised when an end point is the root
+        assert iters == info.iterations
+    # supplying the known end values skips exactly the two initial evaluations
+    (root2, _, _), xs2 = drive(AS.brentq_gen(a, b, fa=f(a), fb=f(b)), f)
+    assert root2 == ref and xs2 == calls[2:]
+
+
+def test_brentq_sign_error():
+    with pytest.raises(ValueError, match='different signs'):
+        drive(AS.brentq_gen(0., 1.), lambda x: 1 + x)
+
+
+def _split_calls(calls, npts):
+    """Split the reference's chi2objfunct log (alpha, nu, value) into per-record lookup tables."""
+    recs, cur, t = [], None, 0
+    for a, nu, v in calls:
+        if a == 0.0 and t < len(npts) and abs(nu - 0.6 * npts[t]) < 1e-9 and (cur is None or len(cur) > 0):
+            cur = {}
+            recs.append(cur)
+            t += 1
+        cur[a] = v + nu                      # chi^2 itself
+    return recs
+
+
+@pytest.mark.parametrize('name', ['fit_k8l2', 'fit_k8l2_c2', 'fit_k8l2_psi', 'fit_default', 'fit_edge'])
+def test_search_logic_on_reference_chi2_values(name):
+    """Gate L5: fed the reference's own chi^2 values, the coroutine takes the same scale factor, the same
+    bracket, requests only alphas the reference evaluated, and lands on the same root (|dlog10| <= 1e-9)."""
+    f = load_golden(name)
+    npts = [int(np.isfinite(v).sum()) for v in f['value']]
+    tables = _split_calls(f['chi2_calls'], npts)
+    assert len(tables) == len(npts)
+    for t, (n, tab) in enumerate(zip(npts, tables)):
+        missing = []
+
+        def chi2(a):
+            if a not in tab:
+                missing.append(a)
+                return float('nan')
+            return tab[a]
+        (outcome, alpha, info), xs = drive(AS.chi2_search_gen(n), chi2)
+        assert not missing, (t, missing[:3])
+        aref = f['alpha'][t]
+        if np.isnan(aref):
+            assert outcome == 'no_root' and np.isnan(alpha)
+            assert len(set(xs)) == 102                       # alpha = 0 .. -101 (memoised across scale factors)
+        elif aref == 0:
+            assert outcome == 'too_smooth' and alpha == 0
+        else:
+            assert outcome == 'root'
+            assert abs(math.log10(alpha) - math.log10(aref)) <= 1e-9
+        # every distinct alpha the reference evaluated for this record is requested exactly once
+        assert sorted(set(xs)) == sorted(tab.keys()) and len(xs) == len(set(xs))
+
+
+def test_run_batched_matches_sequential():
+    rng = np.random.default_rng(0)
+    T = 7
+    roots = rng.uniform(-40, -5, T)
+    npts = [550] * T
+    npts[3] = None                                            # skipped record
+
+    def chi2_of(i, a):
+        # smooth, decreasing in -alpha ... crosses 0.6 * 550 at roots[i]
+        return 330. + 2000. * math.tanh(0.3 * (a - roots[i]))
+
+    counts = []
+
+    def batch(rec, alp):
+        counts.append(len(rec))
+        return np.array([chi2_of(i, a) for i, a in zip(rec, alp)])
+    alphas, outcomes, infos, nev = AS.run_batched(npts, batch, prefetch=8)
+    for i in range(T):
+        if npts[i] is None:
+            assert outcomes[i] == 'skipped' and np.isnan(alphas[i])
+            continue
+        (o, a, info), _ = drive(AS.chi2_search_gen(npts[i]), lambda x: chi2_of(i, x))
+        assert outcomes[i] == o == 'root' and alphas[i] == a
+        assert abs(math.log10(a) - roots[i]) < 1e-10
+    assert nev == sum(counts)
+    # prefetching must cut the number of GPU round trips well below the sequential walk length
+    assert len(counts) < 25

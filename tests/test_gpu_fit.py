@@ -1,0 +1,190 @@
+"""GPU parity of the fit path (normal equations, truncated solves, alpha search, covariance) through the
+C-ABI, stage by stage (SURVEY 8c ladder L3..L7) against the reference's golden vectors and the oracle."""
+import ctypes as C
+import io
+import math
+import os
+import warnings
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from conftest import load_golden, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def make_interp(tmp_path, cfg_text):
+    from volumetricinterp_amd.interpolate import Interpolate
+    p = os.path.join(str(tmp_path), 'config.ini')
+    with open(p, 'w') as f:
+        f.write(cfg_text)
+    return Interpolate(p)
+
+
+def reg_of(f):
+    reg = str(f['reg']) if 'reg' in f.files else None
+    return ({reg: f['R']} if reg else {}), reg
+
+
+def test_L3_normal_equations_on_reference_A():
+    from volumetricinterp_amd import _lib
+    from volumetricinterp_amd.fitengine import FitEngine
+    f = load_golden('fit_k8l2')
+    ctx = _lib.get_context()
+    eng = FitEngine.from_host_basis(ctx, f['rec0_A'], {'curvature': f['R']}, ['curvature'])
+    W = f['error'][0]**-2
+    eng.load_records(np.stack([W, 2 * W]), np.stack([f['value'][0], f['value'][0]]))
+    AWA, y = eng.normal_equations()
+    assert rel(AWA[0], f['rec0_AWA']) <= 1e-13
+    assert rel(y[0], f['rec0_y']) <= 1e-13
+    assert rel(AWA[1], 2 * f['rec0_AWA']) <= 1e-13
+
+
+def solve_direct(X, y, want_H=False):
+    from volumetricinterp_amd import _lib, fitengine  # noqa: F401 (registers signatures)
+    ctx = _lib.get_context()
+    B, N = X.shape[0], X.shape[1]
+    dX, dy = ctx.to_device(X), ctx.to_device(y)
+    dC, drank = ctx.empty((B, N)), ctx.empty((B,), np.int32)
+    dH = ctx.empty((B, N, N)) if want_H else None
+    eps = np.finfo(float).eps
+    _lib.check(_lib.lib.vi_solve_trunc_f64(ctx.handle, B, N, dX.ptr, dy.ptr, None, eps, dC.ptr, drank.ptr, N * eps,
+                                           dH.ptr if want_H else None), 'vi_solve_trunc_f64')
+    return dC.download(), drank.download(), (dH.download() if want_H else None)
+
+
+def test_L4_solve_on_reference_system():
+    f = load_golden('fit_k8l2')
+    C, rank, H = solve_direct(f['rec0_X'][None], f['rec0_y'][None], want_H=True)
+    assert rank[0] == 32
+    assert rel(C[0], f['Coeffs'][0]) <= 1e-6
+    assert rel(H[0], scipy.linalg.pinv(f['rec0_X'])) <= 1e-6
+    dC = H[0] @ f['rec0_AWA'] @ H[0]
+    assert rel(dC, f['Covariance'][0]) <= 1e-5
+
+
+def test_truncated_solve_rank_deficient_indefinite():
+    """gelsd / pinv semantics on symmetric indefinite, rank-deficient systems with an unambiguous gap."""
+    rng = np.random.default_rng(1)
+    B, N = 5, 40
+    X, Y = [], []
+    for i in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        lam = np.concatenate([rng.uniform(0.1, 1, 20) * rng.choice([-1, 1], 20),     # kept, both signs
+                              rng.uniform(1e-9, 1e-6, 10),                            # small but kept
+                              rng.uniform(-1e-20, 1e-20, 10)])                        # below eps*max -> dropped
+        X.append((Q * lam) @ Q.T)
+        Y.append(rng.standard_normal(N))
+    X, Y = np.array(X), np.array(Y)
+    X = 0.5 * (X + X.transpose(0, 2, 1))
+    C, rank, H = solve_direct(X.copy(), Y, want_H=True)
+    for i in range(B):
+        ref, _, rk, _ = scipy.linalg.lstsq(X[i], Y[i])
+        assert rank[i] == rk == 30
+        assert rel(C[i], ref) <= 1e-7
+        assert rel(H[i], scipy.linalg.pinv(X[i])) <= 1e-7
+
+
+@pytest.mark.parametrize('name', ['fit_k8l2', 'fit_k8l2_c2'])
+def test_L7_fit_records_screened(tmp_path, name):
+    """End to end on screened fixtures (reference self-noise < 1e-8): north-star tolerance 1e-6 on the
+    coefficients, same alpha, same chi^2, covariance within 1e-5."""
+    f = load_golden(name)
+    assert np.all(f['self_noise'] < 1e-8)
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    for t in range(f['value'].shape[0]):
+        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 1e-6, t
+        assert rel(res['Covariance'][t], f['Covariance'][t]) <= 1e-5, t
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-6 * f['chi_sq'][t]
+        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-7
+    # work accounting: one solve per distinct alpha (memoised, plus walk prefetch) - far fewer than the reference
+    assert it.fit_stats['solves'] < int(f['evalC_calls'])
+
+
+def test_fit_edge_outcomes(tmp_path):
+    f = load_golden('fit_edge')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    assert res['reg_params'][0][reg] == 0 and f['alpha'][0] == 0             # 'too smooth' -> alpha = 0
+    assert np.isnan(res['reg_params'][1][reg])                               # no root -> NaN row
+    assert np.all(np.isnan(res['Coeffs'][1])) and np.all(np.isnan(res['Covariance'][1])) and np.isnan(res['chi_sq'][1])
+    assert np.array_equal(np.isnan(res['Coeffs']), np.isnan(f['Coeffs']))
+    assert rel(res['Coeffs'][2], f['Coeffs'][2]) <= 1e-6
+    assert abs(res['chi_sq'][0] - f['chi_sq'][0]) <= 1e-6 * f['chi_sq'][0]
+    assert abs(res['chi_sq'][2] - f['chi_sq'][2]) <= 1e-6 * f['chi_sq'][2]
+
+
+def test_nonfinite_weights_give_nan_row(tmp_path):
+    f = load_golden('fit_k8l2')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    value, error = f['value'][:2].copy(), f['error'][:2].copy()
+    error[1, 5] = 0.0                        # W = inf -> lstsq ValueError -> caught -> NaN row (interpolate.py:142-145)
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], value, error, regm)
+    assert np.all(np.isnan(res['Coeffs'][1])) and np.isnan(res['chi_sq'][1])
+    assert rel(res['Coeffs'][0], f['Coeffs'][0]) <= 1e-6
+
+
+def test_public_eval_C_and_find_reg_param(tmp_path):
+    import oracle
+    f = load_golden('fit_k8l2')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    A = f['rec0_A']
+    b, W = f['value'][0], f['error'][0]**-2
+    rp = it.find_reg_param(A, b, W, regm)
+    assert abs(math.log10(rp[reg]) - math.log10(f['alpha'][0])) <= 1e-7
+    C, dC = it.eval_C(A, b, W, regm, {reg: f['alpha'][0]}, calccov=True)
+    Cref, dCref = oracle.eval_C(A, b, W, regm, {reg: f['alpha'][0]}, [reg], calccov=True)
+    assert rel(C, Cref) <= 1e-6 and rel(dC, dCref) <= 1e-5
+    assert rel(it.eval_C(A, b, W, regm, {reg: f['alpha'][0]}), Cref) <= 1e-6
+    nu = 0.6 * len(b)
+    v = it.chi2objfunct(-20., A, b, W, regm, nu, reg)
+    vref = oracle.chi2objfunct(-20., A, b, W, regm, nu, reg, [reg])
+    assert abs(v - vref) <= 1e-6 * abs(vref + nu)
+    with pytest.raises(ValueError):
+        it.eval_C(A, b * np.nan, W, regm, {reg: 1e-20})
+    assert np.isnan(it.find_reg_param(A, b, W * np.inf, regm)[reg])
+    with pytest.raises(NotImplementedError):
+        it.find_reg_param(A, b, W, regm, method='gcv')
+
+
+def test_rbf_fit_no_regularisation(tmp_path):
+    f = load_golden('fit_rbf')
+    it = make_interp(tmp_path, str(f['cfg']))
+    assert it.regularization_list == []
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], {})
+    # coefficients are not reproducible by the reference itself here (self-noise 5e-6 .. 7e-5); chi^2 is
+    for t in range(2):
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-6 * f['chi_sq'][t]
+        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 100 * max(f['self_noise'][t], 1e-6)
+
+
+def test_default_order_report(tmp_path, capsys):
+    """Default order (N = 144): the reference does not reproduce itself (self-noise 7e-2 .. 5e-1 on C),
+    so this reports the build's deviation next to that noise and gates only the stable quantities."""
+    f = load_golden('fit_default')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    from volumetricinterp_amd.estimate import Estimate
+    from volumetricinterp_amd import synth
+    es_a = Estimate.from_arrays(res['Coeffs'], None, f['utime'], f['hull_vert'], str(f['cfg']))
+    es_b = Estimate.from_arrays(f['Coeffs'], None, f['utime'], f['hull_vert'], str(f['cfg']))
+    g = synth.query_grid(8)
+    for t in range(f['value'].shape[0]):
+        dens_a = es_a.evaluate_coeffs(res['Coeffs'][t:t + 1], *g, check_hull=True)[0]
+        dens_b = es_b.evaluate_coeffs(f['Coeffs'][t:t + 1], *g, check_hull=True)[0]
+        ok = np.isfinite(dens_b)
+        with capsys.disabled():
+            print('\n[default order, record %d] rel(C)=%.2e (reference self-noise %.2e)  rel(density in hull)=%.2e  '
+                  'log10 alpha %.6f vs %.6f  chi2 %.6f vs %.6f'
+                  % (t, rel(res['Coeffs'][t], f['Coeffs'][t]), f['self_noise'][t], rel(dens_a[ok], dens_b[ok]),
+                     math.log10(res['reg_params'][t][reg]), math.log10(f['alpha'][t]), res['chi_sq'][t], f['chi_sq'][t]))
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-3 * f['chi_sq'][t]
+        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 0.05

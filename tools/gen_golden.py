@@ -203,8 +203,16 @@ class Recorder:
         def evalC(*a, **k):
             self.evalC_calls += 1
             return oe(*a, **k)
+        self.reg_params = []
+        ofr = it.find_reg_param
+
+        def frp(*a, **k):
+            r = ofr(*a, **k)
+            self.reg_params.append(dict(r))
+            return r
         it.chi2objfunct = chi2obj
         it.eval_C = evalC
+        it.find_reg_param = frp
 
 
 def run_ref_fit(cfg_text, workdir, lat, lon, alt, utime, value, error, regmats, perturb=None):
@@ -264,16 +272,8 @@ def gen_fit(workdir):
         n_evalC = rec.evalC_calls            # snapshot before the extra find_reg_param calls below
         # recover alpha per record from chi2 calls is awkward; recompute via find_reg_param on record 0
         import contextlib
-        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            rp0 = it.find_reg_param(A, value[0], W0, {reg: R}, method='chi2')
-            alphas = []
-            for t in range(T):
-                fin = np.isfinite(value[t])
-                At = A[fin]
-                rp = it.find_reg_param(At, value[t][fin], error[t][fin]**-2, {reg: R}, method='chi2')
-                alphas.append(rp[reg])
-        X0 = AWA + rp0[reg] * R
+        alphas = [rp[reg] for rp in rec.reg_params[:T]]      # the values calc_coeffs itself used
+        X0 = AWA + alphas[0] * R
         print(tag, 'alpha:', alphas, 'self-noise rel(dC):', noise_C, 'evalC calls:', n_evalC)
         save('fit_' + tag, cfg=np.array(cfg), reg=np.array(reg), R=R, lat=lat, lon=lon, alt=alt, utime=utime,
              value=value, error=error, Coeffs=it.Coeffs, Covariance=it.Covariance, chi_sq=it.chi_sq,
@@ -294,11 +294,7 @@ def gen_fit(workdir):
     value[1] = value[1] * (1 + 0.8 * np.sin(np.arange(value.shape[1]) * 0.7)) + 0 * rng.standard_normal(value.shape[1])
     utime = synth.unix_times(3)
     it, rec = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, {'curvature': R})
-    import contextlib
-    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        alphas = [it.find_reg_param(A, value[t], error[t]**-2, {'curvature': R}, method='chi2')['curvature']
-                  for t in range(3)]
+    alphas = [rp['curvature'] for rp in rec.reg_params[:3]]
     print('edge alphas:', alphas, 'chi_sq:', it.chi_sq)
     save('fit_edge', cfg=np.array(cfg), reg=np.array('curvature'), R=R, lat=lat, lon=lon, alt=alt, utime=utime,
          value=value, error=error, Coeffs=it.Coeffs, Covariance=it.Covariance, chi_sq=it.chi_sq,

@@ -148,9 +148,9 @@ class DeviceArray:
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=self.dtype)
-        if host.size != self.size:
-            raise ValueError('upload size mismatch: %d vs %d' % (host.size, self.size))
-        check(lib.vi_h2d(self.ctx.handle, self.ptr, host.ctypes.data_as(VOIDP), self.nbytes), 'vi_h2d')
+        if host.size > self.size:
+            raise ValueError('upload larger than the allocation: %d vs %d' % (host.size, self.size))
+        check(lib.vi_h2d(self.ctx.handle, self.ptr, host.ctypes.data_as(VOIDP), host.nbytes), 'vi_h2d')
         return self
 
     def download(self):

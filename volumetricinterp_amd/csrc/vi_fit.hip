@@ -1,0 +1,299 @@
+// Fit entry points: batched normal equations, regularised minimum-norm solves, chi^2, covariance.
+// Reference: Interpolate.eval_C (volumetricinterp/interpolate.py:432-469) and the chi^2 objective
+// (interpolate.py:255-259).  The basis matrix is shared by all records (geometry is per file, not per
+// record), so T records become one strided-batched contraction instead of T x (#alpha) einsums.
+#include "vi_common.h"
+
+#include <rocsolver/rocsolver.h>
+
+#include <cstdlib>
+
+#define VI_ROCSOLVER(call)                                                                      \
+    do {                                                                                        \
+        rocblas_status s_ = (call);                                                             \
+        if (s_ != rocblas_status_success) {                                                     \
+            vi_set_error("%s:%d: %s -> rocsolver status %d", __FILE__, __LINE__, #call, (int)s_); \
+            return VI_ERR_ROCSOLVER;                                                            \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+// B[t][n][p] = At[n][p] * W[t][p]
+__global__ void k_scale_rows(int64_t P, int N, const double* __restrict__ At, const double* __restrict__ W,
+                             double* __restrict__ B)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y, t = blockIdx.z;
+    if (p >= P) return;
+    B[((int64_t)t * N + n) * P + p] = At[(int64_t)n * P + p] * W[(int64_t)t * P + p];
+}
+
+__global__ void k_mul(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] * b[i];
+}
+
+// X[i] = AWA[rec[i]] + alpha[i] * R   (AWA == nullptr: X[i] += alpha[i] * R, for further penalty terms)
+__global__ void k_form_system(int NN, const double* __restrict__ AWA, const int* __restrict__ rec,
+                              const double* __restrict__ alpha, const double* __restrict__ R, double* __restrict__ X)
+{
+    const int64_t i = blockIdx.x;
+    const int64_t r = rec ? rec[i] : i;
+    const double a = R ? alpha[i] : 0.0;
+    for (int e = threadIdx.x; e < NN; e += blockDim.x) {
+        double v = AWA ? AWA[r * NN + e] : X[i * NN + e];
+        if (R) v = fma(a, R[e], v);
+        X[i * NN + e] = v;
+    }
+}
+
+// One workgroup per system: given eigenpairs (V column-major, lam) form the truncated minimum-norm
+// solution C = V diag(1/lam | |lam| > rcond*max|lam|) V^T y   (gelsd semantics for symmetric X)
+// and optionally the scaled eigenvectors Vs = V diag(w_pinv) for H = Vs V^T.
+template <int BS>
+__global__ __launch_bounds__(BS) void k_trunc_apply(int N, const double* __restrict__ V, const double* __restrict__ lam,
+                                                    const double* __restrict__ y, const int* __restrict__ rec,
+                                                    double rcond, double* __restrict__ C, int* __restrict__ rank,
+                                                    double pinv_rcond, double* __restrict__ Vs)
+{
+    extern __shared__ double sh[];
+    double* g = sh;            // [N] V^T y scaled
+    double* red = sh + N;      // [BS]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const double* Vi = V + (int64_t)i * N * N;
+    const double* li = lam + (int64_t)i * N;
+    const double* yi = y + (int64_t)(rec ? rec[i] : i) * N;
+    // max |lambda|
+    double mx = 0.0;
+    for (int j = tid; j < N; j += BS) mx = fmax(mx, fabs(li[j]));
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = BS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    const double thr = rcond * mx, pthr = pinv_rcond * mx;
+    // g_j = (v_j . y) / lam_j : one wave per eigenvector, coalesced column reads
+    const int wave = tid >> 6, lane = tid & 63, nw = BS >> 6;
+    int rk = 0;
+    for (int j = wave; j < N; j += nw) {
+        double acc = 0.0;
+        for (int r = lane; r < N; r += 64) acc = fma(Vi[(int64_t)j * N + r], yi[r], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) {
+            const bool keep = fabs(li[j]) > thr;
+            g[j] = keep ? acc / li[j] : 0.0;
+            rk += keep ? 1 : 0;
+        }
+    }
+    red[tid] = (double)rk;
+    __syncthreads();
+    for (int s = BS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0 && rank) rank[i] = (int)red[0];
+    __syncthreads();
+    // C_r = sum_j V[r,j] g_j
+    for (int r = tid; r < N; r += BS) {
+        double acc = 0.0;
+        for (int j = 0; j < N; ++j) acc = fma(Vi[(int64_t)j * N + r], g[j], acc);
+        C[(int64_t)i * N + r] = acc;
+    }
+    if (Vs) {
+        double* Vo = Vs + (int64_t)i * N * N;
+        for (int j = 0; j < N; ++j) {
+            const double w = fabs(li[j]) > pthr ? 1.0 / li[j] : 0.0;
+            for (int r = tid; r < N; r += BS) Vo[(int64_t)j * N + r] = Vi[(int64_t)j * N + r] * w;
+        }
+    }
+}
+
+// chi2[i] = sum_p W[rec_i][p] (Rm[i][p] - b[rec_i][p])^2
+template <int BS>
+__global__ __launch_bounds__(BS) void k_chi2(int64_t P, const double* __restrict__ Rm, const int* __restrict__ rec,
+                                             int64_t rec_base, const double* __restrict__ W,
+                                             const double* __restrict__ b, double* __restrict__ chi2)
+{
+    __shared__ double red[BS];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int64_t r = rec ? rec[i] : rec_base + i;
+    const double* Ri = Rm + (int64_t)i * P;
+    const double* Wi = W + r * P;
+    const double* bi = b + r * P;
+    double acc = 0.0;
+    for (int64_t p = tid; p < P; p += BS) {
+        const double d = Ri[p] - bi[p];
+        acc = fma(d * d, Wi[p], acc);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = BS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) chi2[i] = red[0];
+}
+
+int eig_method()
+{
+    static int m = -1;
+    if (m < 0) {
+        const char* e = getenv("VINTERP_EIG");
+        m = 0;
+        if (e && !strcmp(e, "syevj")) m = 1;
+        if (e && !strcmp(e, "syevd")) m = 0;
+    }
+    return m;
+}
+
+}  // namespace
+
+extern "C" int vi_normal_eq_f64(vi_ctx* c, int64_t T, int64_t P, int32_t N, const double* d_At, const double* d_W,
+                                const double* d_b, double* d_AWA, double* d_y)
+{
+    VI_REQUIRE(c && d_At && d_W && d_b && d_AWA && d_y, "null argument");
+    VI_REQUIRE(T >= 0 && P > 0 && N > 0, "bad size");
+    if (T == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    const size_t per_t = (size_t)N * P * sizeof(double);
+    int64_t Tc = (int64_t)((size_t)1 << 30) / (int64_t)per_t;      // <= 1 GiB of scaled copies at a time
+    if (Tc < 1) Tc = 1;
+    if (Tc > T) Tc = T;
+    void* ws = nullptr;
+    const size_t wb_bytes = (size_t)T * P * sizeof(double);
+    int rc = vi_ctx_workspace(c, (size_t)Tc * per_t + wb_bytes, &ws);
+    if (rc != VI_OK) return rc;
+    double* Bs = (double*)ws;
+    double* wb = Bs + (size_t)Tc * N * P;
+    const double one = 1.0, zero = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += Tc) {
+        const int64_t tc = (T - t0) < Tc ? (T - t0) : Tc;
+        hipLaunchKernelGGL(k_scale_rows, dim3(nblk(P, 256), N, (unsigned)tc), dim3(256), 0, c->stream, P, N, d_At,
+                           d_W + t0 * P, Bs);
+        VI_HIP(hipGetLastError());
+        // AWA_t (N x N) = A^T (N x P) * B_t (P x N), column-major views of the row-major N x P arrays
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N,
+                                                 (rocblas_int)P, &one, d_At, (rocblas_int)P, 0, Bs, (rocblas_int)P,
+                                                 (rocblas_stride)N * P, &zero, d_AWA + t0 * N * N, N,
+                                                 (rocblas_stride)N * N, (rocblas_int)tc));
+    }
+    hipLaunchKernelGGL(k_mul, dim3(nblk(T * P, 256)), dim3(256), 0, c->stream, T * P, d_W, d_b, wb);
+    VI_HIP(hipGetLastError());
+    VI_ROCBLAS(rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)T,
+                             (rocblas_int)P, &one, d_At, (rocblas_int)P, wb, (rocblas_int)P, &zero, d_y, N));
+    return VI_OK;
+}
+
+extern "C" int vi_form_system_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
+                                  const double* d_alpha, const double* d_R, double* d_X)
+{
+    VI_REQUIRE(c && d_X, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    VI_REQUIRE(d_AWA || d_R, "nothing to do");
+    VI_REQUIRE(!d_R || d_alpha, "regularisation matrix given without parameters");
+    if (B == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    hipLaunchKernelGGL(k_form_system, dim3((unsigned)B), dim3(256), 0, c->stream, NN, d_AWA, d_rec, d_alpha, d_R, d_X);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, const double* d_y,
+                                  const int32_t* d_rec, double rcond, double* d_C, int32_t* d_rank,
+                                  double pinv_rcond, double* d_H)
+{
+    VI_REQUIRE(c && d_X && d_y && d_C, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    // workspace: eigenvalues [B][N], E [B][N], info [B], (Vs [B][N][N] when H is wanted)
+    const size_t nD = (size_t)B * N;
+    size_t bytes = 2 * nD * sizeof(double) + (size_t)B * sizeof(int) * 4 + 256;
+    if (d_H) bytes += (size_t)B * N * N * sizeof(double);
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, bytes, &ws);
+    if (rc != VI_OK) return rc;
+    double* D = (double*)ws;
+    double* E = D + nD;
+    double* Vs = d_H ? E + nD : nullptr;
+    int* info = (int*)((char*)ws + 2 * nD * sizeof(double) + (d_H ? (size_t)B * N * N * sizeof(double) : 0));
+    if (eig_method() == 1) {
+        int* nsweeps = info + B;
+        double* resid = E;
+        VI_ROCSOLVER(rocsolver_dsyevj_strided_batched(c->blas, rocblas_esort_ascending, rocblas_evect_original,
+                                                      rocblas_fill_upper, N, d_X, N, (rocblas_stride)N * N, 0.0, resid,
+                                                      100, nsweeps, D, N, info, (rocblas_int)B));
+    } else {
+        VI_ROCSOLVER(rocsolver_dsyevd_strided_batched(c->blas, rocblas_evect_original, rocblas_fill_upper, N, d_X, N,
+                                                      (rocblas_stride)N * N, D, N, E, N, info, (rocblas_int)B));
+    }
+    constexpr int BS = 256;
+    const size_t shm = (size_t)(N + BS) * sizeof(double);
+    hipLaunchKernelGGL(k_trunc_apply<BS>, dim3((unsigned)B), dim3(BS), shm, c->stream, N, d_X, D, d_y, d_rec, rcond, d_C,
+                       d_rank, pinv_rcond, Vs);
+    VI_HIP(hipGetLastError());
+    if (d_H) {
+        const double one = 1.0, zero = 0.0;
+        // H = Vs V^T (column-major N x N; symmetric)
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N,
+                                                 &one, Vs, N, (rocblas_stride)N * N, d_X, N, (rocblas_stride)N * N,
+                                                 &zero, d_H, N, (rocblas_stride)N * N, (rocblas_int)B));
+    }
+    return VI_OK;
+}
+
+extern "C" int vi_chi2_f64(vi_ctx* c, int64_t B, int64_t P, int32_t N, const double* d_At, const double* d_C,
+                           const int32_t* d_rec, const double* d_W, const double* d_b, double* d_chi2)
+{
+    VI_REQUIRE(c && d_At && d_C && d_W && d_b && d_chi2, "null argument");
+    VI_REQUIRE(B >= 0 && P > 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    int64_t Bc = (int64_t)((size_t)1 << 29) / (int64_t)(P * sizeof(double));
+    if (Bc < 1) Bc = 1;
+    if (Bc > B) Bc = B;
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)Bc * P * sizeof(double), &ws);
+    if (rc != VI_OK) return rc;
+    double* Rm = (double*)ws;
+    const double one = 1.0, zero = 0.0;
+    for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+        // Rm (P x bc) = A (P x N) * C^T-view (N x bc)
+        VI_ROCBLAS(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (rocblas_int)P,
+                                 (rocblas_int)bc, N, &one, d_At, (rocblas_int)P, d_C + i0 * N, N, &zero, Rm,
+                                 (rocblas_int)P));
+        hipLaunchKernelGGL(k_chi2<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, P, Rm, d_rec ? d_rec + i0 : nullptr,
+                           i0, d_W, d_b, d_chi2 + i0);
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
+extern "C" int vi_cov_f64(vi_ctx* c, int64_t T, int32_t N, const double* d_H, const double* d_AWA, double* d_dC)
+{
+    VI_REQUIRE(c && d_H && d_AWA && d_dC, "null argument");
+    VI_REQUIRE(T >= 0 && N > 0, "bad size");
+    if (T == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)T * N * N * sizeof(double), &ws);
+    if (rc != VI_OK) return rc;
+    double* tmp = (double*)ws;
+    const double one = 1.0, zero = 0.0;
+    const rocblas_stride s = (rocblas_stride)N * N;
+    // all three factors are symmetric, so row-/column-major views coincide
+    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one,
+                                             d_H, N, s, d_AWA, N, s, &zero, tmp, N, s, (rocblas_int)T));
+    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one,
+                                             tmp, N, s, d_H, N, s, &zero, d_dC, N, s, (rocblas_int)T));
+    return VI_OK;
+}

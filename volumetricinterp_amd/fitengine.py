@@ -1,0 +1,217 @@
+"""Batched regularised least-squares fit on the MI355X.
+
+Device-side engine behind ``Interpolate.calc_coeffs`` / ``eval_C`` /
+``find_reg_param`` (reference: volumetricinterp/interpolate.py:97-261, :432-469,
+:511-579).  What changes with respect to the reference's serial record loop:
+
+* the basis matrix is built once per file on the device (N x P layout) and is
+  shared by every record; dropped points (non-finite value, interpolate.py:516-520)
+  enter with W = 0, b = 0, which removes exactly the same terms from every sum;
+* A^T W A and A^T W b are formed once per record (``vi_normal_eq_f64``) instead
+  of once per trial alpha (the reference rebuilds them 367-491 times per record);
+* all (record, alpha) systems requested in one step of the search are formed,
+  eigen-decomposed, truncated and scored in one batch
+  (``vi_form_system_f64`` -> ``vi_solve_trunc_f64`` -> ``vi_chi2_f64``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import alpha_search
+
+EPS = float(np.finfo(np.float64).eps)
+
+_lib._sig('vi_normal_eq_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_form_system_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_solve_trunc_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          C.c_double, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP)
+_lib._sig('vi_chi2_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_cov_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib.EXPORTS += ['vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+
+MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
+
+
+class FitEngine(object):
+    def __init__(self, ctx, At_dev, P, N, reg_matrices, regularization_list):
+        self.ctx = ctx
+        self.At = At_dev
+        self.P, self.N = int(P), int(N)
+        self.regularization_list = list(regularization_list)
+        self.R = {}
+        for name in self.regularization_list:
+            M = np.ascontiguousarray(reg_matrices[name], dtype=np.float64)
+            if M.shape != (self.N, self.N):
+                raise ValueError('regularisation matrix %r has shape %r, expected %r' % (name, M.shape, (N, N)))
+            if not np.all(np.isfinite(M)):
+                raise ValueError('array must not contain infs or NaNs')
+            self.R[name] = ctx.to_device(M)
+        self._bufs = {}
+        self.T = 0
+        self.stats = dict(solves=0, launches=0)
+
+    @classmethod
+    def from_host_basis(cls, ctx, A, reg_matrices, regularization_list):
+        A = np.asarray(A, dtype=np.float64)
+        if A.ndim != 2:
+            raise ValueError('A must be (npoints, nbasis)')
+        if not np.all(np.isfinite(A)):
+            raise ValueError('array must not contain infs or NaNs')
+        At = ctx.to_device(np.ascontiguousarray(A.T))
+        return cls(ctx, At, A.shape[0], A.shape[1], reg_matrices, regularization_list)
+
+    def _buf(self, name, shape, dtype=np.float64):
+        n = int(np.prod(shape, dtype=np.int64))
+        cur = self._bufs.get(name)
+        if cur is None or cur.size < n or cur.dtype != np.dtype(dtype):
+            if cur is not None:
+                cur.free()
+            cur = _lib.DeviceArray(self.ctx, (max(n, 1),), dtype)
+            self._bufs[name] = cur
+        return cur
+
+    # ------------------------------------------------------------------------------------------
+    def load_records(self, W, b):
+        """Upload weights / data of T records (T, P) and form A^T W A, A^T W b for each."""
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if W.shape != b.shape or W.ndim != 2 or W.shape[1] != self.P:
+            raise ValueError('W, b must both be (T, %d)' % self.P)
+        self.T = T = W.shape[0]
+        N = self.N
+        self.dW = self._buf('W', (T, self.P)).upload(W) if T else None
+        self.db = self._buf('b', (T, self.P)).upload(b) if T else None
+        self.dAWA = self._buf('AWA', (T, N, N))
+        self.dy = self._buf('y', (T, N))
+        if T:
+            _lib.check(_lib.lib.vi_normal_eq_f64(self.ctx.handle, T, self.P, N, self.At.ptr, self.dW.ptr, self.db.ptr,
+                                                 self.dAWA.ptr, self.dy.ptr), 'vi_normal_eq_f64')
+
+    def normal_equations(self):
+        """Host copies of A^T W A (T,N,N) and A^T W b (T,N) (for stage-wise parity tests)."""
+        T, N = self.T, self.N
+        AWA = np.empty((T, N, N))
+        y = np.empty((T, N))
+        _lib.check(_lib.lib.vi_d2h(self.ctx.handle, AWA.ctypes.data_as(_lib.VOIDP), self.dAWA.ptr, AWA.nbytes), 'd2h')
+        _lib.check(_lib.lib.vi_d2h(self.ctx.handle, y.ctypes.data_as(_lib.VOIDP), self.dy.ptr, y.nbytes), 'd2h')
+        return AWA, y
+
+    def _solve_chunk(self, rec, alphas, want_H, tag):
+        """Form and solve B systems; returns device C (B,N) [and H (B,N,N)]."""
+        B, N = len(rec), self.N
+        drec = self._buf(tag + 'rec', (B,), np.int32).upload(rec)
+        dX = self._buf(tag + 'X', (B, N, N))
+        first = True
+        for name in self.regularization_list:
+            a = np.ascontiguousarray(alphas[name], dtype=np.float64)
+            dal = self._buf(tag + 'alpha_' + name, (B,)).upload(a)
+            _lib.check(_lib.lib.vi_form_system_f64(self.ctx.handle, B, N, self.dAWA.ptr if first else None,
+                                                   drec.ptr, dal.ptr, self.R[name].ptr, dX.ptr), 'vi_form_system_f64')
+            first = False
+        if first:       # no regularisation at all (radbasfun: REGULARIZATION_LIST empty)
+            _lib.check(_lib.lib.vi_form_system_f64(self.ctx.handle, B, N, self.dAWA.ptr, drec.ptr, None, None, dX.ptr),
+                       'vi_form_system_f64')
+        dC = self._buf(tag + 'C', (B, N))
+        drank = self._buf(tag + 'rank', (B,), np.int32)
+        dH = self._buf(tag + 'H', (B, N, N)) if want_H else None
+        # lstsq: rcond = eps (interpolate.py:462); pinv: rtol = max(M,N) * eps (interpolate.py:465)
+        _lib.check(_lib.lib.vi_solve_trunc_f64(self.ctx.handle, B, N, dX.ptr, self.dy.ptr, drec.ptr, EPS, dC.ptr,
+                                               drank.ptr, N * EPS, dH.ptr if want_H else None), 'vi_solve_trunc_f64')
+        self.stats['solves'] += B
+        self.stats['launches'] += 1
+        return drec, dC, dH, drank
+
+    def chi2_batch(self, rec, alphas):
+        """chi^2 of the regularised solution for B (record, {name: alpha}) pairs -> host array (B,)."""
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        out = np.empty(len(rec))
+        for s in range(0, len(rec), MAX_BATCH):
+            e = min(len(rec), s + MAX_BATCH)
+            B = e - s
+            drec, dC, _, _ = self._solve_chunk(rec[s:e], {k: v[s:e] for k, v in alphas.items()}, False, 's_')
+            dchi = self._buf('s_chi2', (B,))
+            _lib.check(_lib.lib.vi_chi2_f64(self.ctx.handle, B, self.P, self.N, self.At.ptr, dC.ptr, drec.ptr,
+                                            self.dW.ptr, self.db.ptr, dchi.ptr), 'vi_chi2_f64')
+            tmp = np.empty(B)
+            _lib.check(_lib.lib.vi_d2h(self.ctx.handle, tmp.ctypes.data_as(_lib.VOIDP), dchi.ptr, tmp.nbytes), 'd2h')
+            out[s:e] = tmp
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def search(self, npts, prefetch=8):
+        """find_reg_param with method 'chi2' for every loaded record (interpolate.py:97-147).
+
+        npts[t] = number of finite points of record t, or None to skip it.  Returns a list of
+        {name: alpha} dicts (NaN where the search fails) and per-name search info."""
+        T = self.T
+        params = [dict() for _ in range(T)]
+        infos = {}
+        for name in self.regularization_list:
+            def evaluate(rec, log10a, _name=name):
+                al = {n: (np.power(10., log10a) if n == _name else np.zeros(len(rec)))
+                      for n in self.regularization_list}
+                return self.chi2_batch(rec, al)
+            alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch)
+            for t in range(T):
+                params[t][name] = alphas[t]
+            infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
+        return params, infos
+
+    def finalize(self, params, calccov=True):
+        """Final eval_C(calccov=True) + chi^2 for every record (interpolate.py:566-569).
+
+        Records whose parameters contain NaN become NaN rows (interpolate.py:558-563)."""
+        T, N = self.T, self.N
+        Coeffs = np.full((T, N), np.nan)
+        Cov = np.full((T, N, N), np.nan) if calccov else None
+        chi = np.full(T, np.nan)
+        ranks = np.full(T, -1, dtype=np.int32)
+        good = [t for t in range(T) if not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
+        step = max(1, min(len(good), 2048))
+        for s in range(0, len(good), step):
+            idx = np.asarray(good[s:s + step], dtype=np.int32)
+            B = len(idx)
+            al = {n: np.array([params[t][n] for t in idx], dtype=np.float64) for n in self.regularization_list}
+            drec, dC, dH, drank = self._solve_chunk(idx, al, calccov, 'f_')
+            dchi = self._buf('f_chi2', (B,))
+            _lib.check(_lib.lib.vi_chi2_f64(self.ctx.handle, B, self.P, N, self.At.ptr, dC.ptr, drec.ptr, self.dW.ptr,
+                                            self.db.ptr, dchi.ptr), 'vi_chi2_f64')
+            Cb = np.empty((B, N))
+            cb = np.empty(B)
+            rb = np.empty(B, dtype=np.int32)
+            h = self.ctx.handle
+            _lib.check(_lib.lib.vi_d2h(h, Cb.ctypes.data_as(_lib.VOIDP), dC.ptr, Cb.nbytes), 'd2h')
+            _lib.check(_lib.lib.vi_d2h(h, cb.ctypes.data_as(_lib.VOIDP), dchi.ptr, cb.nbytes), 'd2h')
+            _lib.check(_lib.lib.vi_d2h(h, rb.ctypes.data_as(_lib.VOIDP), drank.ptr, rb.nbytes), 'd2h')
+            Coeffs[idx] = Cb
+            chi[idx] = cb
+            ranks[idx] = rb
+            if calccov:
+                # dC = H AWA H needs AWA of the selected records, contiguous
+                dsel = self._buf('f_AWAsel', (B, N, N))
+                _lib.check(_lib.lib.vi_form_system_f64(h, B, N, self.dAWA.ptr, drec.ptr, None, None, dsel.ptr),
+                           'vi_form_system_f64')
+                ddC = self._buf('f_dC', (B, N, N))
+                _lib.check(_lib.lib.vi_cov_f64(h, B, N, dH.ptr, dsel.ptr, ddC.ptr), 'vi_cov_f64')
+                Db = np.empty((B, N, N))
+                _lib.check(_lib.lib.vi_d2h(h, Db.ctypes.data_as(_lib.VOIDP), ddC.ptr, Db.nbytes), 'd2h')
+                Cov[idx] = Db
+        return Coeffs, Cov, chi, ranks
+
+    def fit(self, W, b, npts, calccov=True, prefetch=8):
+        self.load_records(W, b)
+        params, infos = self.search(npts, prefetch=prefetch)
+        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
+
+    def close(self):
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+        for r in self.R.values():
+            r.free()
+        self.R = {}
