@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the fit + evaluate hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: fit ONE record
+(26 beams x 100 ranges, default order MAXK=4 MAXL=6 -> N=144, curvature regularisation, chi^2 search,
+covariance) and evaluate the fitted model on a 128^3 geodetic query grid (BASELINE.json configs[1]).
+Inputs (beam geometry, weights/data, query grid, regularisation matrix) are resident in HBM before the
+timed region; outputs stay on the device.  With --gpus N > 1 every rank runs the same per-GPU workload on
+its own records (independent timesteps: weak scaling, no data-path collective); shared parameters are
+broadcast once from rank 0 over RCCL before the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+CFG = ('[DEFAULT]\nREGULARIZATION_LIST = curvature\nREGULARIZATION_METHOD = chi2\n'
+       '[MODEL]\nNAME = sphharmlag\nMAXK = 4\nMAXL = 6\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\nLONCP = 262\n')
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TF = 78.6       # fp64 vector peak
+EVAL_BYTES_PER_POINT = 32.0    # 3 x 8 B coordinates in + 8 B density out
+EVAL_FLOPS_PER_POINT = 3.0e3   # SURVEY 8d E1 estimate at the default order
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--grid', type=int, default=128, help='query grid edge (128 -> 128^3 points)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(lat, lon, alt, value, error, R, grid_n):
+    """The oracle (faithful CPU restatement of the reference) on a bounded sample of the same workload:
+    the full one-record fit, and a 16^3 sub-grid of the query evaluation scaled to grid_n^3 points."""
+    import oracle                                  # checker / baseline only - never the measured GPU path
+    from volumetricinterp_amd import synth
+    import contextlib
+    import warnings
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:                              # pragma: no cover
+        limiter = contextlib.nullcontext()
+    model = oracle.SphHarmLagOracle()
+    with limiter, warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        t0 = time.perf_counter()
+        counter = [0]
+        C, dC, c2, params = oracle.fit_records(model, lat, lon, alt, value[:1], error[:1], {'curvature': R},
+                                               ['curvature'], counter)
+        t_fit = time.perf_counter() - t0
+        sub = 16
+        g = synth.query_grid(sub)
+        Cv = C[0] if np.all(np.isfinite(C[0])) else np.ones(model.nbasis)
+        t0 = time.perf_counter()
+        oracle.evaluate(model, Cv, *g)
+        t_eval_sub = time.perf_counter() - t0
+    Q = grid_n**3
+    t_eval = t_eval_sub * Q / sub**3
+    return dict(value=Q / (t_fit + t_eval), unit='points/s', cores=1, kind='port',
+                sample='oracle (NumPy/SciPy restatement, 1 BLAS thread): full fit of 1 record 26x100 N=144 '
+                       '(%d eval_C calls, %.1f s) + evaluation of a %d^3 sub-grid (%.2f s) scaled to %d^3 points'
+                       % (counter[0] + 1, t_fit, sub, t_eval_sub, grid_n),
+                fit_seconds=t_fit, eval_points_per_sec=sub**3 / t_eval_sub)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('VINTERP_DEVICE', str(local_rank))
+
+    from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    from volumetricinterp_amd.models.sphharmlag import Model
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    ctx = _lib.get_context(local_rank)
+    model = Model(io.StringIO(CFG), ctx=ctx)
+    h = model.handle(ctx)
+    N = model.nbasis
+
+    # ---- shared parameters: built on rank 0, broadcast once over RCCL (xGMI) ----------------------------
+    nb, nr = synth.GEOM_C2
+    P = nb * nr
+    if rank == 0:
+        lat, lon, alt = synth.beams(nb, nr, seed=0)
+        R = model.eval_reg_matricies['curvature']()
+        shared = np.concatenate([lat, lon, alt, R.ravel()])
+    else:
+        shared = np.empty(3 * P + N * N)
+    if world > 1:
+        import torch
+        tsh = torch.from_numpy(shared).cuda(local_rank)
+        dist.broadcast(tsh, src=0)
+        torch.cuda.synchronize()
+        shared = tsh.cpu().numpy()
+    lat, lon, alt = shared[:P].copy(), shared[P:2 * P].copy(), shared[2 * P:3 * P].copy()
+    R = shared[3 * P:].reshape(N, N).copy()
+
+    # ---- per-rank inputs, made resident before the timed region -----------------------------------------
+    dlat, dlon, dalt = ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(alt)
+    At = model.basis_device(dlat, dlon, dalt, P, transposed=True)
+    A = At.download().T
+    T = 1
+    value, error = synth.synth_records(A, T, seed0=1000 + rank * T)
+    W, b = error**-2., value
+    npts = [P] * T
+    eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
+    eng.upload_records(W, b)
+    g = synth.query_grid(args.grid)
+    Q = g[0].size
+    dq = [ctx.to_device(a.ravel()) for a in g]
+    dC = ctx.empty((T, N))
+    dout = ctx.empty((T, Q))
+
+    fit_ms, eval_ms = [], []
+
+    def step(record=False):
+        t0 = time.perf_counter()
+        res = eng.fit_resident(npts, calccov=True)
+        Cfit = res['Coeffs']
+        if not np.all(np.isfinite(Cfit)):          # NaN row (no root): evaluate zeros, work is the same
+            Cfit = np.nan_to_num(Cfit)
+        dC.upload(Cfit)
+        t1 = time.perf_counter()
+        ctx.timer_start()
+        _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, T, dC.ptr, None, 0, 0., dout.ptr),
+                   'vi_eval_f64')
+        ems = ctx.timer_stop_ms()                  # HIP events on the stream the kernel runs on
+        if record:
+            fit_ms.append((t1 - t0) * 1e3)
+            eval_ms.append(ems)
+        return res
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(record=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        te = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
+        pts = args.steps * Q * T * world
+        out = {
+            'metric': 'fit+eval query-points/sec', 'value': pts / elapsed, 'unit': 'points/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: per GPU 1 record, 26-beam x 100-range fit (N=144, curvature, chi2 '
+                                   'search, covariance) + %d^3 geodetic query grid, fp64' % args.grid,
+                       'points_per_step_per_gpu': Q * T, 'timesteps_per_step_per_gpu': T},
+            'timesteps_per_sec': args.steps * T * world / elapsed,
+            'breakdown_ms': {'fit': float(np.mean(fit_ms)), 'eval_kernel': ev,
+                             'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
+                             'fit_outcome': res['search']['curvature']['outcomes']},
+            'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
+            'roofline': {'kernel': 'k_eval_sph<6,4,1>', 'bound': 'hbm',
+                         'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'traffic': None,
+                         'note': 'fused eval is fp64-VALU-bound (AI ~94 flop/B): %.2f of the %.1f TF fp64 vector peak '
+                                 'at ~3.0 kflop/point' % (EVAL_FLOPS_PER_POINT * Q * T / (ev * 1e-3) / 1e12
+                                                          / FP64_VALU_PEAK_TF, FP64_VALU_PEAK_TF)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
+        elif world == 1:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

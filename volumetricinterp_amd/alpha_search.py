@@ -178,7 +178,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8):
             rec.append(i)
             alp.append(a)
             # walk prefetch: integer alphas continue downwards; harmless extra evaluations
-            if prefetch and a == math.floor(a) and -100. <= a <= -1.:
+            if prefetch and a == math.floor(a) and -100. <= a <= 0.:
                 for k in range(1, prefetch):
                     ak = a - k
                     if ak >= -101. and ak not in cache[i]:

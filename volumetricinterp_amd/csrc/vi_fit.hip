@@ -17,6 +17,13 @@
         }                                                                                       \
     } while (0)
 
+size_t vi_jacobi_lds_bytes(int N);
+size_t vi_jacobi_log_bytes(int N, int max_sweeps);
+bool vi_jacobi_supported(int N);
+int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
+                    const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
+                    int* d_sweeps, double* d_lam);
+
 namespace {
 
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -172,19 +179,23 @@ __global__ __launch_bounds__(BS) void k_chi2(int64_t P, const double* __restrict
     if (tid == 0) chi2[i] = red[0];
 }
 
+// 2: in-LDS parallel Jacobi (vi_jacobi.hip, default where it fits), 1: rocSOLVER syevj, 0: rocSOLVER syevd.
+// syevd (divide & conquer) measured 1.4e-6 on the coefficients of one screened fixture against the 1e-6
+// gate; both Jacobi variants give <= 1e-8.
 int eig_method()
 {
     static int m = -1;
     if (m < 0) {
         const char* e = getenv("VINTERP_EIG");
-        // default: Jacobi (rocSOLVER syevj).  syevd (divide & conquer) is ~3x faster but measured 1.4e-6 on the
-        // coefficients of one screened fixture against a 1e-6 gate, where Jacobi gives <= 1e-8.
-        m = 1;
+        m = 2;
         if (e && !strcmp(e, "syevj")) m = 1;
         if (e && !strcmp(e, "syevd")) m = 0;
+        if (e && !strcmp(e, "jacobi")) m = 2;
     }
     return m;
 }
+
+constexpr int JACOBI_MAX_SWEEPS = 24;
 
 }  // namespace
 
@@ -247,6 +258,27 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
     VI_REQUIRE(B >= 0 && N > 0, "bad size");
     if (B == 0) return VI_OK;
     VI_HIP(hipSetDevice(c->device));
+    if (!d_H && eig_method() == 2 && vi_jacobi_supported(N)) {
+        // in-LDS Jacobi: chunk the batch so that the rotation logs stay within 4 GiB of workspace
+        const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+        int64_t Bc = (int64_t)(((size_t)4 << 30) / logb);
+        if (Bc < 1) Bc = 1;
+        if (Bc > B) Bc = B;
+        void* ws = nullptr;
+        int rc = vi_ctx_workspace(c, (size_t)Bc * logb + (size_t)Bc * sizeof(double) + 256, &ws);
+        if (rc != VI_OK) return rc;
+        double* scl = (double*)((char*)ws + (size_t)Bc * logb);
+        for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+            const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+            double* Xc = d_X + i0 * N * N;
+            hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
+            VI_HIP(hipGetLastError());
+            rc = vi_jacobi_solve(c, bc, N, Xc, scl, d_rec ? d_y : d_y + i0 * N, d_rec ? d_rec + i0 : nullptr, rcond,
+                                 d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, nullptr);
+            if (rc != VI_OK) return rc;
+        }
+        return VI_OK;
+    }
     // workspace: eigenvalues [B][N], E [B][N], info [B], (Vs [B][N][N] when H is wanted)
     const size_t nD = (size_t)B * N;
     size_t bytes = 2 * nD * sizeof(double) + (size_t)B * sizeof(double) + (size_t)B * sizeof(int) * 4 + 256;
@@ -261,7 +293,7 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
     int* info = (int*)((char*)ws + (2 * nD + (size_t)B) * sizeof(double) + (d_H ? (size_t)B * N * N * sizeof(double) : 0));
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
     VI_HIP(hipGetLastError());
-    if (eig_method() == 1) {
+    if (eig_method() >= 1) {
         int* nsweeps = info + B;
         double* resid = E;
         VI_ROCSOLVER(rocsolver_dsyevj_strided_batched(c->blas, rocblas_esort_ascending, rocblas_evect_original,

@@ -75,21 +75,28 @@ class FitEngine(object):
         return cur
 
     # ------------------------------------------------------------------------------------------
-    def load_records(self, W, b):
-        """Upload weights / data of T records (T, P) and form A^T W A, A^T W b for each."""
+    def upload_records(self, W, b):
+        """Make weights / data of T records (T, P) resident on the device."""
         W = np.ascontiguousarray(W, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)
         if W.shape != b.shape or W.ndim != 2 or W.shape[1] != self.P:
             raise ValueError('W, b must both be (T, %d)' % self.P)
         self.T = T = W.shape[0]
-        N = self.N
         self.dW = self._buf('W', (T, self.P)).upload(W) if T else None
         self.db = self._buf('b', (T, self.P)).upload(b) if T else None
+
+    def form_normal_equations(self):
+        """A^T W A (T,N,N) and A^T W b (T,N) of the resident records - once per record, not per alpha."""
+        T, N = self.T, self.N
         self.dAWA = self._buf('AWA', (T, N, N))
         self.dy = self._buf('y', (T, N))
         if T:
             _lib.check(_lib.lib.vi_normal_eq_f64(self.ctx.handle, T, self.P, N, self.At.ptr, self.dW.ptr, self.db.ptr,
                                                  self.dAWA.ptr, self.dy.ptr), 'vi_normal_eq_f64')
+
+    def load_records(self, W, b):
+        self.upload_records(W, b)
+        self.form_normal_equations()
 
     def normal_equations(self):
         """Host copies of A^T W A (T,N,N) and A^T W b (T,N) (for stage-wise parity tests)."""
@@ -142,12 +149,19 @@ class FitEngine(object):
         return out
 
     # ------------------------------------------------------------------------------------------
-    def search(self, npts, prefetch=8):
+    def default_prefetch(self):
+        # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound),
+        # a few steps ahead for large batches (the launch is already full; don't waste solves)
+        return int(max(8, min(102, 2048 // max(1, self.T))))
+
+    def search(self, npts, prefetch=None):
         """find_reg_param with method 'chi2' for every loaded record (interpolate.py:97-147).
 
         npts[t] = number of finite points of record t, or None to skip it.  Returns a list of
         {name: alpha} dicts (NaN where the search fails) and per-name search info."""
         T = self.T
+        if prefetch is None:
+            prefetch = self.default_prefetch()
         params = [dict() for _ in range(T)]
         infos = {}
         for name in self.regularization_list:
@@ -202,7 +216,14 @@ class FitEngine(object):
                 Cov[idx] = Db
         return Coeffs, Cov, chi, ranks
 
-    def fit(self, W, b, npts, calccov=True, prefetch=8):
+    def fit_resident(self, npts, calccov=True, prefetch=None):
+        """Fit the records made resident by upload_records()."""
+        self.form_normal_equations()
+        params, infos = self.search(npts, prefetch=prefetch)
+        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
+
+    def fit(self, W, b, npts, calccov=True, prefetch=None):
         self.load_records(W, b)
         params, infos = self.search(npts, prefetch=prefetch)
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
