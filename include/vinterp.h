@@ -151,6 +151,10 @@ int  vi_chi2_f64(vi_ctx* ctx, int64_t B, int64_t P, int32_t N, const double* d_A
 /* dC[t] = H[t] AWA[t] H[t]   (interpolate.py:466) */
 int  vi_cov_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_H, const double* d_AWA, double* d_dC);
 
+/* Diagnostic: eigenvalues (unsorted) of B symmetric N x N systems by the in-LDS Jacobi kernel that
+ * vi_solve_trunc_f64 uses, and the sweeps each system needed.  d_X is rescaled in place. */
+int  vi_eigvals_f64(vi_ctx* ctx, int64_t B, int32_t N, double* d_X, double* d_lam, int32_t* d_sweeps);
+
 #ifdef __cplusplus
 }
 #endif

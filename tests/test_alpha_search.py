@@ -128,3 +128,41 @@ def test_run_batched_matches_sequential():
     assert nev == sum(counts)
     # prefetching must cut the number of GPU round trips well below the sequential walk length
     assert len(counts) < 25
+
+
+@pytest.mark.parametrize('case', range(len(FUNCS) - 1))
+@pytest.mark.parametrize('K', [15, 255])
+def test_multisection_finds_brents_root(case, K):
+    f, a, b = FUNCS[case]
+    ref = scipy.optimize.brentq(f, a, b)
+    g = AS.multisection_gen(a, b, f(a), f(b), K)
+    rounds = 0
+    try:
+        xs = next(g)
+        while True:
+            rounds += 1
+            assert len(xs) == K
+            xs = g.send([f(x) for x in xs])
+    except StopIteration as stop:
+        root, nr, calls = stop.value
+    assert abs(root - ref) <= 4e-12 + 4e-15 * abs(ref)
+    assert nr == rounds and rounds <= math.ceil(math.log((b - a) / 2e-12) / math.log(K + 1)) + 1
+
+
+def test_search_with_multisection_on_smooth_chi2():
+    roots = [-12.3456789, -33.3]
+    for rt in roots:
+        chi2 = lambda a: 330. + 2000. * math.tanh(0.3 * (a - rt))       # noqa: E731
+        (o1, a1, _), xs1 = drive(AS.chi2_search_gen(550), chi2)
+        g = AS.chi2_search_gen(550, multisection=63)
+        nreq = 0
+        try:
+            x = next(g)
+            while True:
+                nreq += 1 if isinstance(x, tuple) else 0
+                x = g.send([chi2(v) for v in x] if isinstance(x, tuple) else chi2(x))
+        except StopIteration as stop:
+            o2, a2, info = stop.value
+        assert o1 == o2 == 'root'
+        assert abs(math.log10(a1) - math.log10(a2)) <= 1e-11
+        assert nreq <= 7                            # 64^-7 < 2e-12: dependent rounds after the walk

@@ -86,11 +86,53 @@ def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
     raise RuntimeError('Failed to converge after %d iterations.' % maxiter)
 
 
-def chi2_search_gen(npts):
+def multisection_gen(xa, xb, fa, fb, K, xtol=XTOL):
+    """Latency-optimised replacement for the sequential Brent iteration when the GPU is otherwise idle
+    (a single record): every round evaluates K equispaced interior points of the current bracket *in one
+    batch* and keeps the sub-interval with the sign change nearest to xb, shrinking the bracket by K+1 per
+    round until it is shorter than xtol; the root is then the secant point of the last bracket.  For a
+    continuous objective it returns the same root as brentq to within xtol (2e-12 in log10 alpha), in
+    ceil(log(1/xtol)/log(K+1)) rounds (5 for K = 255) instead of Brent's 10-30 dependent evaluations.
+
+    Yields a tuple of K abscissae, receives the K function values.  Returns (root, rounds, funcalls)."""
+    lo, hi, flo, fhi = xa, xb, fa, fb
+    if flo == 0:
+        return lo, 0, 0
+    if fhi == 0:
+        return hi, 0, 0
+    if _signbit(flo) == _signbit(fhi):
+        raise ValueError('f(a) and f(b) must have different signs')
+    rounds = funcalls = 0
+    while abs(hi - lo) > xtol:
+        xs = tuple(lo + (hi - lo) * (k + 1) / (K + 1) for k in range(K))
+        fs = yield xs
+        rounds += 1
+        funcalls += K
+        pts = [(lo, flo)] + list(zip(xs, fs)) + [(hi, fhi)]
+        # scan from the xb end for the first sign change
+        for j in range(len(pts) - 1, 0, -1):
+            (x0, f0), (x1, f1) = pts[j - 1], pts[j]
+            if f1 == 0:
+                return x1, rounds, funcalls
+            if f0 == 0:
+                return x0, rounds, funcalls
+            if _signbit(f0) != _signbit(f1):
+                lo, flo, hi, fhi = x0, f0, x1, f1
+                break
+        else:                                   # NaNs: cannot narrow any further
+            break
+        if rounds > 60:
+            break
+    root = lo - flo * (hi - lo) / (fhi - flo) if fhi != flo else 0.5 * (lo + hi)
+    return root, rounds, funcalls
+
+
+def chi2_search_gen(npts, multisection=0):
     """Coroutine form of Interpolate.chi2 (interpolate.py:152-218) for one record.
 
-    Yields log10(alpha), receives chi^2 at that alpha.  Returns (outcome, alpha, info) with outcome in
-    {'too_smooth', 'no_root', 'root'}; alpha is 0, NaN or 10**root as in the reference."""
+    Yields log10(alpha) (or a tuple of them), receives chi^2 at that alpha (or a list).  Returns
+    (outcome, alpha, info) with outcome in {'too_smooth', 'no_root', 'root'}; alpha is 0, NaN or 10**root as
+    in the reference.  multisection = K > 0 replaces the Brent iteration by K-point multisection."""
     memo = {}
 
     def f_at(a):                       # sub-generator: memoised chi^2(a)
@@ -123,18 +165,28 @@ def chi2_search_gen(npts):
             break
     if not bracket:
         return 'no_root', float('nan'), dict(sf=None)
-    br = brentq_gen(alpha, alpha0, fa=val, fb=val0)
-    try:
-        x = next(br)
-        while True:
-            x = br.send((yield from f_at(x)) - nu)
-    except StopIteration as stop:
-        root, iters, _ = stop.value
+    if multisection:
+        ms = multisection_gen(alpha, alpha0, val, val0, int(multisection))
+        try:
+            xs = next(ms)
+            while True:
+                chis = yield xs
+                xs = ms.send([c - nu for c in chis])
+        except StopIteration as stop:
+            root, iters, _ = stop.value
+    else:
+        br = brentq_gen(alpha, alpha0, fa=val, fb=val0)
+        try:
+            x = next(br)
+            while True:
+                x = br.send((yield from f_at(x)) - nu)
+        except StopIteration as stop:
+            root, iters, _ = stop.value
     return 'root', float(np.power(10., root)), dict(sf=sf_used, bracket=(alpha, alpha0), log10_alpha=root,
                                                      iterations=iters)
 
 
-def run_batched(npts_list, chi2_batch, prefetch=8):
+def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
     """Drive one search coroutine per record against a batched chi^2 evaluator.
 
     npts_list[i]: number of finite data points of record i (``len(b)``, interpolate.py:175), or None to
@@ -150,7 +202,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8):
         if n is None:
             results[i] = ('skipped', float('nan'), {})
             continue
-        g = chi2_search_gen(n)
+        g = chi2_search_gen(n, multisection=multisection)
         gens[i] = g
         pending[i] = next(g)
 
@@ -168,13 +220,23 @@ def run_batched(npts_list, chi2_batch, prefetch=8):
             progressed = False
             for i in list(pending):
                 a = pending[i]
-                if a in cache[i]:
+                if isinstance(a, tuple):
+                    if all(x in cache[i] for x in a):
+                        advance(i, [cache[i][x] for x in a])
+                        progressed = True
+                elif a in cache[i]:
                     advance(i, cache[i][a])
                     progressed = True
         if not gens:
             break
         rec, alp = [], []
         for i, a in pending.items():
+            if isinstance(a, tuple):
+                for x in a:
+                    if x not in cache[i]:
+                        rec.append(i)
+                        alp.append(x)
+                continue
             rec.append(i)
             alp.append(a)
             # walk prefetch: integer alphas continue downwards; harmless extra evaluations

@@ -365,3 +365,29 @@ extern "C" int vi_cov_f64(vi_ctx* c, int64_t T, int32_t N, const double* d_H, co
                                              tmp, N, s, d_H, N, s, &zero, d_dC, N, s, (rocblas_int)T));
     return VI_OK;
 }
+
+// Diagnostic / test entry: eigenvalues of B symmetric systems by the in-LDS Jacobi kernel, with the number
+// of sweeps each one took.  d_X is scaled in place (power of two) and otherwise only read.
+extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, double* d_lam, int32_t* d_sweeps)
+{
+    VI_REQUIRE(c && d_X && d_lam, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    if (!vi_jacobi_supported(N)) {
+        vi_set_error("vi_eigvals_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipSetDevice(c->device));
+    const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)B * logb + (size_t)B * (N + 1) * sizeof(double) * 2 + 256, &ws);
+    if (rc != VI_OK) return rc;
+    double* scl = (double*)((char*)ws + (size_t)B * logb);
+    double* yz = scl + B;            // zero right-hand sides
+    double* Cz = yz + (size_t)B * N;
+    VI_HIP(hipMemsetAsync(yz, 0, (size_t)B * N * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
+    VI_HIP(hipGetLastError());
+    return vi_jacobi_solve(c, B, N, d_X, scl, yz, nullptr, 2.220446049250313e-16, Cz, nullptr, ws,
+                           JACOBI_MAX_SWEEPS, d_sweeps, d_lam);
+}

@@ -14,6 +14,7 @@ Device-side engine behind ``Interpolate.calc_coeffs`` / ``eval_C`` /
   (``vi_form_system_f64`` -> ``vi_solve_trunc_f64`` -> ``vi_chi2_f64``).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -31,7 +32,8 @@ _lib._sig('vi_solve_trunc_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.
 _lib._sig('vi_chi2_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_cov_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib.EXPORTS += ['vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -154,7 +156,19 @@ class FitEngine(object):
         # a few steps ahead for large batches (the launch is already full; don't waste solves)
         return int(max(8, min(102, 2048 // max(1, self.T))))
 
-    def search(self, npts, prefetch=None):
+    def default_multisection(self):
+        mode = os.environ.get('VINTERP_ROOT', 'auto')
+        if mode == 'brent':
+            return 0
+        # opt-in only: chi^2(alpha) - nu is not monotone (the curvature matrix is indefinite) and can cross zero
+        # several times inside one unit bracket; Brent's iterate sequence decides which root the reference
+        # returns (measured on the screened MAXK=8, MAXL=2 fixture: roots at -28.4698 and -28.0745 in [-29,-28]),
+        # so any other root finder breaks parity.  Multisection is kept for latency experiments.
+        if mode == 'multisection':
+            return int(max(15, min(255, 256 // max(1, self.T) - 1)))
+        return 0
+
+    def search(self, npts, prefetch=None, multisection=None):
         """find_reg_param with method 'chi2' for every loaded record (interpolate.py:97-147).
 
         npts[t] = number of finite points of record t, or None to skip it.  Returns a list of
@@ -162,6 +176,8 @@ class FitEngine(object):
         T = self.T
         if prefetch is None:
             prefetch = self.default_prefetch()
+        if multisection is None:
+            multisection = self.default_multisection()
         params = [dict() for _ in range(T)]
         infos = {}
         for name in self.regularization_list:
@@ -169,7 +185,8 @@ class FitEngine(object):
                 al = {n: (np.power(10., log10a) if n == _name else np.zeros(len(rec)))
                       for n in self.regularization_list}
                 return self.chi2_batch(rec, al)
-            alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch)
+            alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
+                                                                   multisection=multisection)
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
@@ -216,16 +233,16 @@ class FitEngine(object):
                 Cov[idx] = Db
         return Coeffs, Cov, chi, ranks
 
-    def fit_resident(self, npts, calccov=True, prefetch=None):
+    def fit_resident(self, npts, calccov=True, prefetch=None, multisection=None):
         """Fit the records made resident by upload_records()."""
         self.form_normal_equations()
-        params, infos = self.search(npts, prefetch=prefetch)
+        params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
-    def fit(self, W, b, npts, calccov=True, prefetch=None):
+    def fit(self, W, b, npts, calccov=True, prefetch=None, multisection=None):
         self.load_records(W, b)
-        params, infos = self.search(npts, prefetch=prefetch)
+        params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
