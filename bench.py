@@ -89,13 +89,8 @@ def main():
     from volumetricinterp_amd.fitengine import FitEngine
     from volumetricinterp_amd.models.sphharmlag import Model
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+    from volumetricinterp_amd.parallel import Comm
+    comm = Comm(backend='nccl' if world > 1 else None)      # "nccl" is RCCL on ROCm; no-op for one process
 
     ctx = _lib.get_context(local_rank)
     model = Model(io.StringIO(CFG), ctx=ctx)
@@ -105,20 +100,12 @@ def main():
     # ---- shared parameters: built on rank 0, broadcast once over RCCL (xGMI) ----------------------------
     nb, nr = synth.GEOM_C2
     P = nb * nr
+    shared = {}
     if rank == 0:
         lat, lon, alt = synth.beams(nb, nr, seed=0)
-        R = model.eval_reg_matricies['curvature']()
-        shared = np.concatenate([lat, lon, alt, R.ravel()])
-    else:
-        shared = np.empty(3 * P + N * N)
-    if world > 1:
-        import torch
-        tsh = torch.from_numpy(shared).cuda(local_rank)
-        dist.broadcast(tsh, src=0)
-        torch.cuda.synchronize()
-        shared = tsh.cpu().numpy()
-    lat, lon, alt = shared[:P].copy(), shared[P:2 * P].copy(), shared[2 * P:3 * P].copy()
-    R = shared[3 * P:].reshape(N, N).copy()
+        shared = dict(lat=lat, lon=lon, alt=alt, R=model.eval_reg_matricies['curvature']())
+    shared = comm.broadcast_arrays(shared)
+    lat, lon, alt, R = shared['lat'], shared['lon'], shared['alt'], shared['R']
 
     # ---- per-rank inputs, made resident before the timed region -----------------------------------------
     dlat, dlon, dalt = ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(alt)
@@ -157,10 +144,7 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        comm.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -169,12 +153,7 @@ def main():
     for _ in range(args.steps):
         res = step(record=True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
 
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
@@ -205,8 +184,7 @@ def main():
         elif world == 1:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == '__main__':
