@@ -157,6 +157,13 @@ def main():
 
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
+        traffic = None                 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+        try:
+            pmc = json.load(open(os.path.join(REPO, 'profiles', 'r1_eval_pmc.json')))
+            if pmc.get('points_per_launch') == Q * T:
+                traffic = pmc['hbm_bytes_per_launch']
+        except Exception:
+            pass
         pts = args.steps * Q * T * world
         out = {
             'metric': 'fit+eval query-points/sec', 'value': pts / elapsed, 'unit': 'points/s',
@@ -174,7 +181,7 @@ def main():
             'roofline': {'kernel': 'k_eval_sph<6,4,1>', 'bound': 'hbm',
                          'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'traffic': None,
+                         'traffic': traffic,
                          'note': 'fused eval is fp64-VALU-bound (AI ~94 flop/B): %.2f of the %.1f TF fp64 vector peak '
                                  'at ~3.0 kflop/point' % (EVAL_FLOPS_PER_POINT * Q * T / (ev * 1e-3) / 1e12
                                                           / FP64_VALU_PEAK_TF, FP64_VALU_PEAK_TF)},
