@@ -234,6 +234,7 @@ extern "C" int vi_model_create(vi_ctx* c, const vi_model_desc* d, vi_model** out
             if (rc != VI_OK) break;
             hg[g].v0 = G.v0;
             hg[g].nvmax = G.nvmax;
+            if (g == 0) m->nvmax0 = G.nvmax;
             hg[g].nterms = G.nterms;
             const size_t nj = (size_t)G.nvmax + 1;
             if ((rc = upload(m, G.pick, nj, &hg[g].pick)) != VI_OK) break;

@@ -9,6 +9,8 @@
 // served by the scalar data path / LDS broadcast and never costs per-lane HBM traffic.
 #include "vi_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -281,6 +283,167 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph(SphDev M, int64_t Q, const d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2 fast path: exact template orders (L = MAXL, K = MAXK), one degree group.  Differences to the generic
+// kernel above, all aimed at keeping the fp64 VALU busy (the kernel is VALU-bound):
+//  * the recurrence table c[j][m] and the coefficient tile are staged in LDS once per workgroup and read as
+//    wave-uniform (broadcast) ds_read_b128 - no dependent scalar loads in the inner loop;
+//  * the triangular start-up (degrees j <= L) is unrolled at compile time, so the main degree loop has no
+//    branches: 2 fp64 ops per (degree, order);
+//  * the loop over l is unrolled, so each contraction knows l at compile time (no predication).
+template <int L, int K, int TT>
+struct FastEval {
+    const double* shC;      // LDS [TT][L*L*K] coefficient tile, [t][r = l(l+1)+m][k]
+    double Lk[K];
+    double acc[TT];
+    template <int l>
+    __device__ __forceinline__ void consume(const double* cur, const double* cm, const double* sm)
+    {
+        constexpr int r0 = l * (l + 1);
+        constexpr int NB = L * L * K;
+#pragma unroll
+        for (int m = 0; m <= l; ++m) {
+            const double pc = cur[m] * cm[m];
+            const double ps = cur[m] * sm[m];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const double* cp = shC + t * NB + (r0 + m) * K;
+                const double* cn = shC + t * NB + (r0 - m) * K;
+                double Sp = 0.0, Sm = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    Sp = fma(cp[k], Lk[k], Sp);
+                    if (m > 0) Sm = fma(cn[k], Lk[k], Sm);
+                }
+                acc[t] = fma(pc, Sp, acc[t]);
+                if (m > 0) acc[t] = fma(ps, Sm, acc[t]);
+            }
+        }
+    }
+};
+
+template <int L, int K, int TT, int l>
+struct ConsumeAt {
+    // consume degree l if its integer part equals j (start-up phase only: j <= L)
+    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const int* nvl, int j, const double* cur,
+                                               const double* cm, const double* sm)
+    {
+        if (nvl[l] == j) E.template consume<l>(cur, cm, sm);
+        if constexpr (l + 1 < L) ConsumeAt<L, K, TT, l + 1>::run(E, nvl, j, cur, cm, sm);
+    }
+};
+
+template <int L, int K, int TT, int l>
+struct MainSegments {
+    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const double* shc, const int* nvl, int& j, double x,
+                                               double* cur, double* prev, const double* cm, const double* sm)
+    {
+        const int jend = nvl[l];
+        if (jend > L) {
+#pragma unroll 2
+            for (; j <= jend; ++j) {
+                const double* cj = shc + j * L;
+#pragma unroll
+                for (int m = 0; m < L; ++m) {
+                    const double nw = fma(x, cur[m], -(cj[m] * prev[m]));
+                    prev[m] = cur[m];
+                    cur[m] = nw;
+                }
+            }
+            E.template consume<l>(cur, cm, sm);
+        }
+        if constexpr (l + 1 < L) MainSegments<L, K, TT, l + 1>::run(E, shc, nvl, j, x, cur, prev, cm, sm);
+    }
+};
+
+template <int L, int K, int TT>
+__global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, const double* __restrict__ lat,
+                                                         const double* __restrict__ lon, const double* __restrict__ alt,
+                                                         int tcount, const double* __restrict__ Cp,
+                                                         const double* __restrict__ hull, int F, double tol,
+                                                         double* __restrict__ out)
+{
+    extern __shared__ __align__(16) double sh[];
+    constexpr int NB = L * L * K;
+    const SphGroupDev G = M.groups[0];
+    const int nj = G.nvmax + 1;
+    double* shc = sh;                                   // [nj][L]
+    double* shC = sh + ((nj * L + 1) & ~1);             // [TT][NB]
+    int* nvl = reinterpret_cast<int*>(shC + TT * NB);   // [L]
+    for (int i = threadIdx.x; i < nj * L; i += BLOCK) shc[i] = G.c[i];
+    for (int i = threadIdx.x; i < TT * NB; i += BLOCK) shC[i] = i < tcount * NB ? Cp[i] : 0.0;
+    for (int j = threadIdx.x; j < nj; j += BLOCK) {
+        const int l = G.pick[j];
+        if (l >= 0) nvl[l] = j;
+    }
+    __syncthreads();
+
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t qc = q < Q ? q : Q - 1;
+    const Geom g = sph_geom(M, lat[qc], lon[qc], alt[qc]);
+    bool in = true;
+    if (F > 0) {
+        in = inside_hull(hull, F, tol, g.X, g.Y, g.Z);
+        if (!__any(in && q < Q)) {
+            if (q < Q)
+                for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
+            return;
+        }
+    }
+    FastEval<L, K, TT> E;
+    E.shC = shC;
+    laguerre<K>(K, g.z, E.Lk);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) E.acc[t] = 0.0;
+    double cm[L], sm[L];
+    cm[0] = 1.0;
+    sm[0] = 0.0;
+#pragma unroll
+    for (int m = 1; m < L; ++m) {
+        cm[m] = cm[m - 1] * g.cphi - sm[m - 1] * g.sphi;
+        sm[m] = sm[m - 1] * g.cphi + cm[m - 1] * g.sphi;
+    }
+    const double x = g.x;
+    const double zz = 0.5 * (1.0 - x);
+    const bool intseed = (G.nterms == 0);
+    double cur[L], prev[L];
+#pragma unroll
+    for (int m = 0; m < L; ++m) { cur[m] = 0.0; prev[m] = 0.0; }
+    double pmm = 1.0, spow = 1.0;
+    // ---- start-up: degrees j = 0 .. L, compile-time triangular structure ------------------------------
+#pragma unroll
+    for (int j = 0; j <= L; ++j) {
+#pragma unroll
+        for (int m = 0; m < L; ++m) {
+            if (j > m + 1) {
+                if (j < nj) {
+                    const double nw = fma(x, cur[m], -(shc[j * L + m] * prev[m]));
+                    prev[m] = cur[m];
+                    cur[m] = nw;
+                }
+            } else if (j == m) {
+                if (m > 0) { pmm *= -(2.0 * m - 1.0) * g.s; spow *= g.s; }
+                if (intseed) cur[m] = pmm;
+                else cur[m] = G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz);
+            } else if (j == m + 1) {
+                prev[m] = cur[m];
+                if (intseed) cur[m] = x * (2.0 * m + 1.0) * cur[m];
+                else cur[m] = G.pref[L + m] * spow * hyp_series(G.q + (size_t)(L + m) * G.nterms, G.nterms, zz);
+            }
+        }
+        ConsumeAt<L, K, TT, 0>::run(E, nvl, j, cur, cm, sm);
+    }
+    // ---- main: all chains in recurrence mode; one segment per degree l --------------------------------
+    int j = L + 1;
+    MainSegments<L, K, TT, 0>::run(E, shc, nvl, j, x, cur, prev, cm, sm);
+    const double Ez = exp(-0.5 * g.z);
+    if (q < Q) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < tcount) out[(int64_t)t * Q + q] = in ? Ez * E.acc[t] : __builtin_nan("");
+    }
+}
+
 // Cp[t][r*maxk + k] = C[t][k*L2 + r] * scale[r]
 __global__ void k_prep_coef(int T, int maxk, int L2, const double* __restrict__ C, const double* __restrict__ scale,
                             double* __restrict__ Cp)
@@ -403,6 +566,46 @@ int launch_eval_sph(vi_model* m, int64_t Q, const double* lat, const double* lon
     return VI_OK;
 }
 
+
+template <int L, int K>
+int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
+                         const double* Cp, const double* hull, int F, double tol, double* out)
+{
+    const int N = m->N;
+    const int nj = m->nvmax0 + 1;
+    auto shm = [&](int TT) { return (size_t)(((nj * L + 1) & ~1) + TT * N) * sizeof(double) + L * sizeof(int) + 16; };
+    static bool attr = false;
+    if (!attr) {
+        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    int64_t t = 0;
+    while (t < T) {
+        if (T - t >= 4) {
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 4>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
+                               m->sph, Q, lat, lon, alt, 4, Cp + t * N, hull, F, tol, out + t * Q);
+            t += 4;
+        } else {
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 1>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(1), m->ctx->stream,
+                               m->sph, Q, lat, lon, alt, 1, Cp + t * N, hull, F, tol, out + t * Q);
+            t += 1;
+        }
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
+bool use_fast_eval()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VINTERP_EVAL");
+        v = (e && !strcmp(e, "generic")) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -467,6 +670,18 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
                            m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
         VI_HIP(hipGetLastError());
         const int L = m->sph.maxl, K = m->sph.maxk;
+        if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
+#define VI_FAST(LL, KK) \
+    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out)
+            VI_FAST(6, 4);
+            VI_FAST(2, 8);
+            VI_FAST(3, 4);
+            VI_FAST(4, 3);
+            VI_FAST(3, 2);
+            VI_FAST(12, 2);
+            VI_FAST(12, 8);
+#undef VI_FAST
+        }
         if (L <= 6 && K <= 4)
             return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
         if (L <= 12 && K <= 8)

@@ -80,6 +80,7 @@ struct vi_model {
     int kind = 0;
     int N = 0;
     SphDev sph{};
+    int nvmax0 = 0;              // nvmax of the first degree group (host copy, for LDS sizing)
     RbfDev rbf{};
     std::vector<void*> allocs;   // device allocations owned by the model
     double* d_coef = nullptr;    // reordered + scaled coefficient staging for vi_eval (grow-only)

@@ -25,14 +25,31 @@
 //    truncation is going to drop anyway; a sweep without rotations ends the iteration.
 #include "vi_common.h"
 
+#ifdef VI_STAMPS
+// diagnostic build only (make STAMPS=1): per-phase cycle sums of workgroup 0, wave 0
+__device__ unsigned long long g_jacobi_stamps[8];
+#define VI_STAMP(k)                                                                   \
+    do {                                                                              \
+        const unsigned long long t_ = __builtin_readcyclecounter();                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_jacobi_stamps[k] += t_ - stamp_t;  \
+        stamp_t = __builtin_readcyclecounter();                                       \
+    } while (0)
+#else
+#define VI_STAMP(k)
+#endif
+
 namespace {
 
 constexpr int JBS = 512;              // 8 waves: two per SIMD, so LDS latency of one hides under the other
 
-__device__ __host__ __forceinline__ int tri(int i, int j)      // index into the packed lower triangle
+// Index into the packed lower triangle.  Inside a row the even columns are stored first, then the odd ones:
+// the 2x2 blocks of consecutive lanes then sit 8 B apart (columns 2P, 2P+2, ...) instead of 16 B, which makes
+// the ds_read_b64 / ds_write_b64 streams of a round bank-conflict free.
+__device__ __host__ __forceinline__ int tri(int i, int j)
 {
-    const int a = i > j ? i : j, b = i > j ? j : i;
-    return ((a * (a + 1)) >> 1) + b;
+    const int r = i > j ? i : j, c = i > j ? j : i;
+    const int off = (c & 1) ? ((r + 2) >> 1) + (c >> 1) : (c >> 1);
+    return ((r * (r + 1)) >> 1) + off;
 }
 
 // slot permutation applied after every round (Brent & Luk): slot 0 is fixed, the others advance along the
@@ -65,6 +82,7 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
     double* yv = A + ntri;                                                   // [2][Np] double-buffered
     double2* cs = reinterpret_cast<double2*>(yv + 2 * Np + (ntri & 1));      // [m], 16-B aligned
     double* nd = reinterpret_cast<double*>(cs + m);                          // [8] reduction scratch
+    const int trash0 = (int)((nd + 8) - A);                                  // [4 (IT JBS - nblk)] idle block slots
 
     const int tid = threadIdx.x;
     const int64_t sys = blockIdx.x;
@@ -75,14 +93,14 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
     // ---- load (slot s holds original index slot_orig0(s)) ----------------------------------------
     double mxd = 0.0;
     for (int e = tid; e < ntri; e += JBS) {
-        // e -> (row, col) of the packed triangle
+        // e -> (row, col) of the lower triangle (enumeration order only; the LDS position is tri(row, col))
         int row = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (((row + 1) * (row + 2)) / 2 <= e) ++row;
         while ((row * (row + 1)) / 2 > e) --row;
         const int col = e - (row * (row + 1)) / 2;
         const int oi = slot_orig0(row, m), oj = slot_orig0(col, m);
         const double v = (oi < N && oj < N) ? Xs[(int64_t)oi * N + oj] : 0.0;
-        A[e] = v;
+        A[tri(row, col)] = v;
         if (row == col) mxd = fmax(mxd, fabs(v));
     }
     for (int s = tid; s < Np; s += JBS) {
@@ -100,16 +118,21 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         while ((Q * (Q - 1)) / 2 > k) --Q;
         while (((Q + 1) * Q) / 2 <= k) ++Q;
         const int P = k - (Q * (Q - 1)) / 2;
-        bQ[it] = k < nblk ? Q : -1;
-        bP[it] = P;
-        // element (a, b) of B_PQ = A(slot 2P+a, slot 2Q+b)
+        const bool live = k < nblk;
+        bQ[it] = live ? Q : 0;
+        bP[it] = live ? P : 0;
+        // element (a, b) of B_PQ = A(slot 2P+a, slot 2Q+b); idle block slots of the last iteration work on a
+        // private scratch quadruple so that the loop body needs no predication
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
-                src[it][2 * a + b2] = tri(2 * P + a, 2 * Q + b2);
-                dst[it][2 * a + b2] = tri(slot_next(2 * P + a, m), slot_next(2 * Q + b2, m));
+                src[it][2 * a + b2] = live ? tri(2 * P + a, 2 * Q + b2) : trash0 + 4 * (k - nblk) + 2 * a + b2;
+                dst[it][2 * a + b2] = live ? tri(slot_next(2 * P + a, m), slot_next(2 * Q + b2, m))
+                                           : trash0 + 4 * (k - nblk) + 2 * a + b2;
             }
+        if (!live)
+            for (int e = 0; e < 4; ++e) A[src[it][e]] = 0.0;
     }
     // diagonal block of my pair (threads < m)
     const int p0 = 2 * tid, p1 = 2 * tid + 1;
@@ -127,9 +150,13 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
     const int rps = 2 * m - 1;            // rounds per sweep
     int sweep = 0, ycur = 0;
     int64_t nround = 0;
+#ifdef VI_STAMPS
+    unsigned long long stamp_t = __builtin_readcyclecounter();
+#endif
     for (; sweep < max_sweeps; ++sweep) {
         int rotated = 0;
         for (int r = 0; r < rps; ++r, ++nround) {
+            VI_STAMP(7);
             // ---- phase 1 (first m threads): rotation of every pair ------------------------------------
             double npp = 0.0, nqq = 0.0, npq = 0.0;
             if (tid < m) {
@@ -155,27 +182,31 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
                 cs[tid] = make_double2(c, s);
                 logp[nround * m + tid] = make_double2(c, s);
             }
+            VI_STAMP(0);
             // ---- phase 2a (all threads, overlaps phase 1 of the other waves): fetch my blocks ------------
             double b[IT][4];
 #pragma unroll
             for (int it = 0; it < IT; ++it)
-                if (bQ[it] >= 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[it][e] = A[src[it][e]];
-                }
+                for (int e = 0; e < 4; ++e) b[it][e] = A[src[it][e]];
+            VI_STAMP(1);
             __syncthreads();
+            VI_STAMP(2);
             // ---- phase 2b: B_PQ <- R_P^T B_PQ R_Q, stored at the permuted slots -----------------------------
+            double2 rp[IT], rq[IT];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                if (bQ[it] >= 0) {
-                    const double2 rp = cs[bP[it]], rq = cs[bQ[it]];
-                    const double t11 = rp.x * b[it][0] - rp.y * b[it][2], t12 = rp.x * b[it][1] - rp.y * b[it][3];
-                    const double t21 = rp.y * b[it][0] + rp.x * b[it][2], t22 = rp.y * b[it][1] + rp.x * b[it][3];
-                    A[dst[it][0]] = rq.x * t11 - rq.y * t12;
-                    A[dst[it][1]] = rq.y * t11 + rq.x * t12;
-                    A[dst[it][2]] = rq.x * t21 - rq.y * t22;
-                    A[dst[it][3]] = rq.y * t21 + rq.x * t22;
-                }
+                rp[it] = cs[bP[it]];
+                rq[it] = cs[bQ[it]];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const double t11 = rp[it].x * b[it][0] - rp[it].y * b[it][2], t12 = rp[it].x * b[it][1] - rp[it].y * b[it][3];
+                const double t21 = rp[it].y * b[it][0] + rp[it].x * b[it][2], t22 = rp[it].y * b[it][1] + rp[it].x * b[it][3];
+                A[dst[it][0]] = rq[it].x * t11 - rq[it].y * t12;
+                A[dst[it][1]] = rq[it].y * t11 + rq[it].x * t12;
+                A[dst[it][2]] = rq[it].x * t21 - rq[it].y * t22;
+                A[dst[it][3]] = rq[it].y * t21 + rq[it].x * t22;
             }
             if (tid < m) {
                 A[dpp] = npp;
@@ -183,7 +214,9 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
                 A[dpq] = npq;
             }
             ycur ^= 1;
+            VI_STAMP(3);
             __syncthreads();
+            VI_STAMP(4);
         }
         if (!__syncthreads_or(rotated)) { ++sweep; break; }
     }
@@ -220,29 +253,53 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         if (rank) rank[sys] = (int)tot;
         if (sweeps_out) sweeps_out[sys] = sweep;
     }
+    VI_STAMP(5);
     // ---- C = V g : undo (permutation, rotation) round by round, one barrier per round --------------------
-    constexpr int PF = 16;                              // rounds of (c, s) prefetched per batch
-    for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
-        const int nb = r1 >= PF ? PF : (int)r1;
-        double2 pf[PF];
-        if (tid < m) {
+    // Done by wave 0 alone: the DS operations of one wave execute in order, so the write -> read hand-over between
+    // consecutive rounds needs no workgroup barrier (which cost ~1.1k cycles per round with 8 waves, 31 % of the
+    // kernel).  Lane l owns pairs l and l + 64.
+    if (tid < 64) {
+        constexpr int PF = 8;                           // rounds of (c, s) prefetched per batch
+        const int P1 = tid + 64;
+        const bool has1 = P1 < m, has0 = tid < m;
+        const int q0 = 2 * P1, q1 = 2 * P1 + 1;
+        const int m0 = slot_next(has1 ? q0 : 0, m), m1 = slot_next(has1 ? q1 : 1, m);
+        for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
+            const int nb = r1 >= PF ? PF : (int)r1;
+            double2 pf0[PF], pf1[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u)
-                if (u < nb) pf[u] = logp[(r1 - 1 - u) * m + tid];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (u < nb) {
-                if (tid < m) {
-                    const double gp = yc[n0], gq = yc[n1];       // values that slots p0, p1 were moved to
-                    yo[p0] = pf[u].x * gp + pf[u].y * gq;        // g <- J g
-                    yo[p1] = -pf[u].y * gp + pf[u].x * gq;
+            for (int u = 0; u < PF; ++u) {
+                if (u < nb) {
+                    if (has0) pf0[u] = logp[(r1 - 1 - u) * m + tid];
+                    if (has1) pf1[u] = logp[(r1 - 1 - u) * m + P1];
                 }
-                double* t = yc; yc = yo; yo = t;
-                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (u < nb) {
+                    if (has0) {
+                        const double gp = yc[n0], gq = yc[n1];       // values that slots p0, p1 were moved to
+                        yo[p0] = pf0[u].x * gp + pf0[u].y * gq;      // g <- J g
+                        yo[p1] = -pf0[u].y * gp + pf0[u].x * gq;
+                    }
+                    if (has1) {
+                        const double gp = yc[m0], gq = yc[m1];
+                        yo[q0] = pf1[u].x * gp + pf1[u].y * gq;
+                        yo[q1] = -pf1[u].y * gp + pf1[u].x * gq;
+                    }
+                    double* t = yc; yc = yo; yo = t;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
+        if (yc != yv + ycur * Np) ycur ^= 1;          // which buffer holds the result
     }
+    // broadcast the parity of the final buffer from wave 0 (nd[0] is free now)
+    if (tid == 0) nd[0] = (double)ycur;
+    __syncthreads();
+    yc = yv + ((int)nd[0]) * Np;
+    VI_STAMP(6);
     for (int s = tid; s < Np; s += JBS) {
         const int o = slot_orig0(s, m);
         if (o < N) C[sys * N + o] = yc[s];
@@ -251,11 +308,29 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
 
 }  // namespace
 
+#ifdef VI_STAMPS
+extern "C" int vi_debug_jacobi_stamps(double* out, int reset)
+{
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_jacobi_stamps), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_jacobi_stamps), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 size_t vi_jacobi_lds_bytes(int N)
 {
     const int Np = (N + 1) & ~1, m = Np / 2;
     const int nt = Np * (Np + 1) / 2;
+    const int nblk = m * (m - 1) / 2;
+    int iters = (nblk + JBS - 1) / JBS;
+    iters = iters <= 1 ? 1 : iters <= 2 ? 2 : iters <= 5 ? 5 : 10;      // the instantiated IT (vi_jacobi_solve)
     size_t b = (size_t)(nt + 2 * Np + (nt & 1)) * 8 + (size_t)m * 16 + 8 * 8;
+    b += (size_t)4 * (iters * JBS - nblk) * 8;       // scratch quadruples of the idle block slots
     return (b + 15) & ~(size_t)15;
 }
 
