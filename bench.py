@@ -178,7 +178,7 @@ def main():
                              'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
                              'fit_outcome': res['search']['curvature']['outcomes']},
             'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
-            'roofline': {'kernel': 'k_eval_sph<6,4,1>', 'bound': 'hbm',
+            'roofline': {'kernel': 'k_eval_sph_fast<6,4,1>', 'bound': 'hbm',
                          'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'traffic': traffic,

@@ -22,7 +22,9 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps);
 bool vi_jacobi_supported(int N);
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam);
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround);
+bool vi_jacobi_vectors_supported(int N);
+int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V);
 
 namespace {
 
@@ -274,8 +276,49 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
             hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
             VI_HIP(hipGetLastError());
             rc = vi_jacobi_solve(c, bc, N, Xc, scl, d_rec ? d_y : d_y + i0 * N, d_rec ? d_rec + i0 : nullptr, rcond,
-                                 d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, nullptr);
+                                 d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, nullptr, 0,
+                                 nullptr);
             if (rc != VI_OK) return rc;
+        }
+        return VI_OK;
+    }
+    if (d_H && eig_method() == 2 && vi_jacobi_vectors_supported(N)) {
+        // final solves with H = pinv(X): in-LDS Jacobi (C, eigenvalues, rotation log) -> eigenvectors from the
+        // log -> H = V diag(1/lam | kept) V^T
+        const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+        int64_t Bc = (int64_t)(((size_t)4 << 30) / logb);
+        if (Bc < 1) Bc = 1;
+        if (Bc > B) Bc = B;
+        void* ws = nullptr;
+        const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * N * N * sizeof(double);
+        int rc = vi_ctx_workspace(c, (size_t)Bc * per + 1024, &ws);
+        if (rc != VI_OK) return rc;
+        char* wp = (char*)ws + (size_t)Bc * logb;
+        double* scl = (double*)wp;
+        double* lam = scl + Bc;
+        double* V = lam + (size_t)Bc * N;
+        double* Vs = V + (size_t)Bc * N * N;
+        int* nrd = (int*)(Vs + (size_t)Bc * N * N);
+        const double one = 1.0, zero = 0.0;
+        for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+            const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+            double* Xc = d_X + i0 * N * N;
+            const double* yc = d_rec ? d_y : d_y + i0 * N;
+            const int* rc_ = d_rec ? d_rec + i0 : nullptr;
+            hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
+            VI_HIP(hipGetLastError());
+            rc = vi_jacobi_solve(c, bc, N, Xc, scl, yc, rc_, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
+                                 JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd);
+            if (rc != VI_OK) return rc;
+            rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, V);
+            if (rc != VI_OK) return rc;
+            constexpr int BS = 256;
+            hipLaunchKernelGGL(k_trunc_apply<BS>, dim3((unsigned)bc), dim3(BS), (size_t)(N + BS) * sizeof(double), c->stream,
+                               N, V, lam, scl, yc, rc_, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, pinv_rcond, Vs);
+            VI_HIP(hipGetLastError());
+            VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N,
+                                                     &one, Vs, N, (rocblas_stride)N * N, V, N, (rocblas_stride)N * N, &zero,
+                                                     d_H + i0 * N * N, N, (rocblas_stride)N * N, (rocblas_int)bc));
         }
         return VI_OK;
     }
@@ -389,5 +432,5 @@ extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, doub
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
     VI_HIP(hipGetLastError());
     return vi_jacobi_solve(c, B, N, d_X, scl, yz, nullptr, 2.220446049250313e-16, Cz, nullptr, ws,
-                           JACOBI_MAX_SWEEPS, d_sweeps, d_lam);
+                           JACOBI_MAX_SWEEPS, d_sweeps, d_lam, 0, nullptr);
 }

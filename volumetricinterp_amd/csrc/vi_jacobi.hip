@@ -71,7 +71,8 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
                                                       double* __restrict__ C, int* __restrict__ rank,
                                                       double2* __restrict__ rotlog, int64_t log_stride,
                                                       int max_sweeps, int* __restrict__ sweeps_out,
-                                                      double* __restrict__ lam_out)
+                                                      double* __restrict__ lam_out, int lam_raw,
+                                                      int* __restrict__ nround_out)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int Np = (N + 1) & ~1;          // padded to even with an inert index
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         yc[i] = keep ? yc[i] / (lam * sc) : 0.0;
         rk += keep ? 1 : 0;
         // the padding index is an exact zero eigenvalue and is never kept; eigenvalues leave unsorted
-        if (lam_out && i < N) lam_out[sys * N + i] = lam * sc;
+        // (slot order; with lam_raw the eigenvalues of the scaled system, as k_trunc_apply expects)
+        if (lam_out && i < N) lam_out[sys * N + i] = lam_raw ? lam : lam * sc;
     }
     __syncthreads();                            // nd is reused below
     for (int o = 32; o > 0; o >>= 1) rk += __shfl_xor(rk, o);
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         for (int w = 0; w < JBS / 64; ++w) tot += nd[w];
         if (rank) rank[sys] = (int)tot;
         if (sweeps_out) sweeps_out[sys] = sweep;
+        if (nround_out) nround_out[sys] = (int)nround;
     }
     VI_STAMP(5);
     // ---- C = V g : undo (permutation, rotation) round by round, one barrier per round --------------------
@@ -306,6 +309,74 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
     }
 }
 
+
+// Eigenvectors from the rotation log: V = J_1 J_2 ... J_K, so column k of V is the reverse replay applied to
+// the unit vector of (final) slot k.  One workgroup per (system, block of CW columns); the CW vectors sit in
+// LDS as G[slot][CW]; rotations are staged from HBM RB rounds at a time.  Output is the LAPACK/rocSOLVER
+// layout Vout[k*N + r] (eigenvector k contiguous), k = final slot, r = original index.  Even N only.
+template <int CW>
+__global__ __launch_bounds__(JBS) void k_jacobi_vectors(int N, const double2* __restrict__ rotlog, int64_t log_stride,
+                                                        const int* __restrict__ nround_in, double* __restrict__ Vout)
+{
+    constexpr int RB = 16;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int m = N >> 1;
+    double* G = reinterpret_cast<double*>(lds_raw);                 // [N][CW]
+    double2* st = reinterpret_cast<double2*>(G + (size_t)N * CW);    // [RB][m]
+    const int tid = threadIdx.x;
+    const int64_t sys = blockIdx.x;
+    const int c0 = blockIdx.y * CW;
+    const double2* logp = rotlog + sys * log_stride;
+    const int nround = nround_in[sys];
+    for (int i = tid; i < N * CW; i += JBS) {
+        const int s = i / CW, c = i - s * CW;
+        G[i] = (s == c0 + c) ? 1.0 : 0.0;
+    }
+    constexpr int ITV = 8;                                           // items per thread: m*CW <= ITV*JBS
+    const int nitems = m * CW;
+    int iP[ITV], ic[ITV];
+#pragma unroll
+    for (int it = 0; it < ITV; ++it) {
+        const int i = tid + it * JBS;
+        iP[it] = i < nitems ? i / CW : -1;
+        ic[it] = i - (i / CW) * CW;
+    }
+    __syncthreads();
+    for (int r1 = nround; r1 > 0; r1 -= RB) {
+        const int nb = r1 >= RB ? RB : r1;
+        for (int i = tid; i < nb * m; i += JBS) {
+            const int u = i / m, P = i - u * m;
+            st[u * m + P] = logp[(int64_t)(r1 - 1 - u) * m + P];
+        }
+        __syncthreads();
+        for (int u = 0; u < nb; ++u) {
+            double gp[ITV], gq[ITV];
+#pragma unroll
+            for (int it = 0; it < ITV; ++it)
+                if (iP[it] >= 0) {
+                    const int P = iP[it];
+                    gp[it] = G[slot_next(2 * P, m) * CW + ic[it]];
+                    gq[it] = G[slot_next(2 * P + 1, m) * CW + ic[it]];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITV; ++it)
+                if (iP[it] >= 0) {
+                    const int P = iP[it];
+                    const double2 r = st[u * m + P];
+                    G[(2 * P) * CW + ic[it]] = r.x * gp[it] + r.y * gq[it];
+                    G[(2 * P + 1) * CW + ic[it]] = -r.y * gp[it] + r.x * gq[it];
+                }
+            __syncthreads();
+        }
+    }
+    double* Vo = Vout + sys * (int64_t)N * N;
+    for (int i = tid; i < N * CW; i += JBS) {
+        const int c = i / N, s = i - c * N;                          // s fastest: contiguous stores
+        if (c0 + c < N) Vo[(int64_t)(c0 + c) * N + slot_orig0(s, m)] = G[s * CW + c];
+    }
+}
+
 }  // namespace
 
 #ifdef VI_STAMPS
@@ -354,7 +425,7 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps)
 template <int IT>
 static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                          const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                         int* d_sweeps, double* d_lam)
+                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround)
 {
     const size_t shm = vi_jacobi_lds_bytes(N);
     static size_t attr_max = 0;
@@ -368,7 +439,7 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
     // eigenvalue (|lambda| > eps * max|lambda|) by more than 1e-6 of itself; chasing them only burns sweeps
     const double abs_floor = 1e-22;
     hipLaunchKernelGGL(k_jacobi_solve<IT>, dim3((unsigned)B), dim3(JBS), shm, c->stream, N, d_X, d_scl, d_y, d_rec,
-                       rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam);
+                       rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround);
     VI_HIP(hipGetLastError());
     return VI_OK;
 }
@@ -376,13 +447,37 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
 // d_X: systems scaled by k_scale_system (B x N x N, only read).
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam)
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround)
 {
     const int it = jacobi_iters(N);
-#define VI_J(IT) return launch_jacobi<IT>(c, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam)
+#define VI_J(IT) return launch_jacobi<IT>(c, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround)
     if (it <= 1) VI_J(1);
     if (it <= 2) VI_J(2);
     if (it <= 5) VI_J(5);
     VI_J(10);
 #undef VI_J
+}
+
+// Eigenvectors (column k = eigenvector of slot k, LAPACK layout) from the rotation logs of vi_jacobi_solve.
+bool vi_jacobi_vectors_supported(int N) { return vi_jacobi_supported(N) && (N % 2 == 0) && N <= 192; }
+
+int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
+{
+    constexpr int CW = 36;
+    const int m = N / 2;
+    if (m * CW > 8 * JBS) {
+        vi_set_error("vi_jacobi_vectors: N=%d too large", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    const size_t shm = (size_t)N * CW * sizeof(double) + (size_t)16 * m * sizeof(double2);
+    static size_t attr_max = 0;
+    if (shm > attr_max) {
+        VI_HIP(hipFuncSetAttribute((const void*)k_jacobi_vectors<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_max = shm;
+    }
+    const int64_t log_stride = (int64_t)max_sweeps * (N - 1) * m;
+    hipLaunchKernelGGL(k_jacobi_vectors<CW>, dim3((unsigned)B, (unsigned)((N + CW - 1) / CW)), dim3(JBS), shm, c->stream, N,
+                       (const double2*)d_log, log_stride, d_nround, d_V);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
 }
