@@ -151,6 +151,20 @@ int  vi_chi2_f64(vi_ctx* ctx, int64_t B, int64_t P, int32_t N, const double* d_A
 /* dC[t] = H[t] AWA[t] H[t]   (interpolate.py:466) */
 int  vi_cov_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_H, const double* d_AWA, double* d_dC);
 
+/* ---- warm-started regularisation-parameter search ----------------------------------------------
+ * Brent's iterates (interpolate.py:214) solve nearly identical systems X(alpha) = AWA[rec] + alpha R.
+ * vi_warm_prepare_f64 decomposes X(alpha0[i]) of B records with eigenvectors (returning the solution C
+ * at alpha0 like vi_solve_trunc_f64) and stores V, D1 = V^T AWA V, D2 = V^T R V, yt = V^T y per record
+ * (slot i); vi_warm_solve_f64 then solves (D1 + alpha D2) c' = yt for B (slot, alpha) pairs with the same
+ * truncation rule and returns C = V c'.  Used for the chi^2 search only; the final coefficients of a
+ * record always come from vi_solve_trunc_f64 on the untransformed system. */
+int  vi_warm_prepare_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
+                         const double* d_alpha0, const double* d_R, const double* d_y, double rcond,
+                         double* d_C, int32_t* d_rank, double* d_V, double* d_D1, double* d_D2, double* d_yt);
+int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, const double* d_D2,
+                       const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
+                       double rcond, double* d_C, int32_t* d_rank);
+
 /* Diagnostic: eigenvalues (unsorted) of B symmetric N x N systems by the in-LDS Jacobi kernel that
  * vi_solve_trunc_f64 uses, and the sweeps each system needed.  d_X is rescaled in place. */
 int  vi_eigvals_f64(vi_ctx* ctx, int64_t B, int32_t N, double* d_X, double* d_lam, int32_t* d_sweeps);

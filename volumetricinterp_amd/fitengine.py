@@ -32,8 +32,12 @@ _lib._sig('vi_solve_trunc_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.
 _lib._sig('vi_chi2_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_cov_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_warm_prepare_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -151,6 +155,79 @@ class FitEngine(object):
         return out
 
     # ------------------------------------------------------------------------------------------
+    # ---- warm-started chi^2 evaluation for the Brent phase ------------------------------------------
+    def warm_enabled(self):
+        if os.environ.get('VINTERP_WARM', '1') == '0':
+            return False
+        return self.N % 2 == 0 and 8 <= self.N <= 180
+
+    def _warm_reset(self):
+        self._warm_slot = {}
+
+    def chi2_batch_search(self, rec, log10a, name):
+        """chi^2 for the search of `name` (all other parameters zero), B requests.  Integer log10(alpha) (the
+        bracket walk) are solved cold; the first non-integer request of a record (Brent's first iterate) is solved
+        cold *with eigenvectors*, which sets up the record's rotated system; later iterates use it."""
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        log10a = np.asarray(log10a, dtype=np.float64)
+        B, N, T = len(rec), self.N, self.T
+        is_int = log10a == np.floor(log10a)
+        if not self.warm_enabled() or len(set(rec[~is_int].tolist())) != int((~is_int).sum()):
+            al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
+            return self.chi2_batch(rec, al)
+        alpha = np.power(10., log10a)
+        warm = np.array([(not i) and (r in self._warm_slot) for r, i in zip(rec.tolist(), is_int.tolist())], dtype=bool)
+        prep = (~is_int) & (~warm)
+        cold = is_int
+        order = np.concatenate([np.nonzero(cold)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
+        nc, npre, nw = int(cold.sum()), int(prep.sum()), int(warm.sum())
+        h = self.ctx.handle
+        dCall = self._buf('w_C', (B, N))
+        drank = self._buf('w_rank', (B,), np.int32)
+        rec_o, alpha_o = rec[order], alpha[order]
+        drec = self._buf('w_rec', (B,), np.int32).upload(rec_o)
+        dal = self._buf('w_alpha', (B,)).upload(alpha_o)
+        if nc:
+            dX = self._buf('w_X', (min(nc, MAX_BATCH), N, N))
+            for s0 in range(0, nc, MAX_BATCH):
+                bc = min(MAX_BATCH, nc - s0)
+                _lib.check(_lib.lib.vi_form_system_f64(h, bc, N, self.dAWA.ptr, drec.offset_ptr(s0), dal.offset_ptr(s0),
+                                                       self.R[name].ptr, dX.ptr), 'vi_form_system_f64')
+                _lib.check(_lib.lib.vi_solve_trunc_f64(h, bc, N, dX.ptr, self.dy.ptr, drec.offset_ptr(s0), EPS,
+                                                       dCall.offset_ptr(s0 * N), drank.offset_ptr(s0), N * EPS, None),
+                           'vi_solve_trunc_f64')
+        if npre or nw:
+            dV = self._buf('w_V', (T, N, N))
+            dD1 = self._buf('w_D1', (T, N, N))
+            dD2 = self._buf('w_D2', (T, N, N))
+            dyt = self._buf('w_yt', (T, N))
+        if npre:
+            slot0 = len(self._warm_slot)
+            for k, r in enumerate(rec_o[nc:nc + npre].tolist()):
+                self._warm_slot[r] = slot0 + k
+            _lib.check(_lib.lib.vi_warm_prepare_f64(h, npre, N, self.dAWA.ptr, drec.offset_ptr(nc), dal.offset_ptr(nc),
+                                                    self.R[name].ptr, self.dy.ptr, EPS, dCall.offset_ptr(nc * N),
+                                                    drank.offset_ptr(nc), dV.offset_ptr(slot0 * N * N),
+                                                    dD1.offset_ptr(slot0 * N * N), dD2.offset_ptr(slot0 * N * N),
+                                                    dyt.offset_ptr(slot0 * N)), 'vi_warm_prepare_f64')
+        if nw:
+            slots = np.array([self._warm_slot[r] for r in rec_o[nc + npre:].tolist()], dtype=np.int32)
+            dslot = self._buf('w_slot', (nw,), np.int32).upload(slots)
+            _lib.check(_lib.lib.vi_warm_solve_f64(h, nw, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, dslot.ptr,
+                                                  dal.offset_ptr(nc + npre), EPS, dCall.offset_ptr((nc + npre) * N),
+                                                  drank.offset_ptr(nc + npre)), 'vi_warm_solve_f64')
+        dchi = self._buf('w_chi2', (B,))
+        _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dCall.ptr, drec.ptr, self.dW.ptr, self.db.ptr,
+                                        dchi.ptr), 'vi_chi2_f64')
+        tmp = np.empty(B)
+        _lib.check(_lib.lib.vi_d2h(h, tmp.ctypes.data_as(_lib.VOIDP), dchi.ptr, tmp.nbytes), 'd2h')
+        out = np.empty(B)
+        out[order] = tmp
+        self.stats['solves'] += B
+        self.stats['launches'] += 1
+        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw
+        return out
+
     def default_prefetch(self):
         # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound),
         # a few steps ahead for large batches (the launch is already full; don't waste solves)
@@ -181,10 +258,10 @@ class FitEngine(object):
         params = [dict() for _ in range(T)]
         infos = {}
         for name in self.regularization_list:
+            self._warm_reset()
+
             def evaluate(rec, log10a, _name=name):
-                al = {n: (np.power(10., log10a) if n == _name else np.zeros(len(rec)))
-                      for n in self.regularization_list}
-                return self.chi2_batch(rec, al)
+                return self.chi2_batch_search(rec, log10a, _name)
             alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
                                                                    multisection=multisection)
             for t in range(T):
