@@ -22,7 +22,7 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps);
 bool vi_jacobi_supported(int N);
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround);
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor);
 bool vi_jacobi_vectors_supported(int N);
 int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V);
 
@@ -240,6 +240,7 @@ int eig_method()
 }
 
 constexpr int JACOBI_MAX_SWEEPS = 24;
+constexpr double JACOBI_FLOOR_COLD = 1e-22, JACOBI_FLOOR_WARM = 1e-16;
 
 }  // namespace
 
@@ -319,7 +320,7 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
             VI_HIP(hipGetLastError());
             rc = vi_jacobi_solve(c, bc, N, Xc, scl, d_rec ? d_y : d_y + i0 * N, d_rec ? d_rec + i0 : nullptr, rcond,
                                  d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, nullptr, 0,
-                                 nullptr);
+                                 nullptr, JACOBI_FLOOR_COLD);
             if (rc != VI_OK) return rc;
         }
         return VI_OK;
@@ -350,7 +351,7 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
             hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
             VI_HIP(hipGetLastError());
             rc = vi_jacobi_solve(c, bc, N, Xc, scl, yc, rc_, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
-                                 JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd);
+                                 JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd, JACOBI_FLOOR_COLD);
             if (rc != VI_OK) return rc;
             rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, V);
             if (rc != VI_OK) return rc;
@@ -474,7 +475,7 @@ extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, doub
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
     VI_HIP(hipGetLastError());
     return vi_jacobi_solve(c, B, N, d_X, scl, yz, nullptr, 2.220446049250313e-16, Cz, nullptr, ws,
-                           JACOBI_MAX_SWEEPS, d_sweeps, d_lam, 0, nullptr);
+                           JACOBI_MAX_SWEEPS, d_sweeps, d_lam, 0, nullptr, JACOBI_FLOOR_COLD);
 }
 
 // ---- warm-started search -------------------------------------------------------------------------------
@@ -509,7 +510,8 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     hipLaunchKernelGGL(k_form_system, dim3((unsigned)B), dim3(256), 0, c->stream, NN, d_AWA, d_rec, d_alpha0, d_R, T0);
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, NN, T0, scl);
     VI_HIP(hipGetLastError());
-    rc = vi_jacobi_solve(c, B, N, T0, scl, d_y, d_rec, rcond, d_C, d_rank, ws, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd);
+    rc = vi_jacobi_solve(c, B, N, T0, scl, d_y, d_rec, rcond, d_C, d_rank, ws, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd,
+                         JACOBI_FLOOR_COLD);
     if (rc != VI_OK) return rc;
     rc = vi_jacobi_vectors(c, B, N, ws, JACOBI_MAX_SWEEPS, nrd, d_V);
     if (rc != VI_OK) return rc;
@@ -564,7 +566,7 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
         hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, X, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, d_slot + i0, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
-                             JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr);
+                             JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_slot + i0, cp, d_C + i0 * N);

@@ -425,7 +425,7 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps)
 template <int IT>
 static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                          const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround)
+                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor)
 {
     const size_t shm = vi_jacobi_lds_bytes(N);
     static size_t attr_max = 0;
@@ -435,9 +435,9 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
     }
     const int Np = (N + 1) & ~1, m = Np / 2;
     const int64_t log_stride = (int64_t)max_sweeps * (Np - 1) * m;
-    // the systems are scaled to max|X| in [1, 2): off-diagonal elements below 1e-22 cannot move any kept
-    // eigenvalue (|lambda| > eps * max|lambda|) by more than 1e-6 of itself; chasing them only burns sweeps
-    const double abs_floor = 1e-22;
+    // abs_floor: the systems are scaled to max|X| in [1, 2).  Cold solves pass 1e-22: off-diagonal elements
+    // below it cannot move any kept eigenvalue (|lambda| > eps * max|lambda|) by more than 1e-6 of itself.
+    // Warm solves pass 1e-16: the rotated system D1 + alpha D2 carries formation errors of N*eps anyway.
     hipLaunchKernelGGL(k_jacobi_solve<IT>, dim3((unsigned)B), dim3(JBS), shm, c->stream, N, d_X, d_scl, d_y, d_rec,
                        rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround);
     VI_HIP(hipGetLastError());
@@ -447,10 +447,10 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
 // d_X: systems scaled by k_scale_system (B x N x N, only read).
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround)
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor)
 {
     const int it = jacobi_iters(N);
-#define VI_J(IT) return launch_jacobi<IT>(c, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround)
+#define VI_J(IT) return launch_jacobi<IT>(c, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor)
     if (it <= 1) VI_J(1);
     if (it <= 2) VI_J(2);
     if (it <= 5) VI_J(5);
@@ -461,9 +461,9 @@ int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double
 // Eigenvectors (column k = eigenvector of slot k, LAPACK layout) from the rotation logs of vi_jacobi_solve.
 bool vi_jacobi_vectors_supported(int N) { return vi_jacobi_supported(N) && (N % 2 == 0) && N <= 192; }
 
-int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
+template <int CW>
+static int launch_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
 {
-    constexpr int CW = 36;
     const int m = N / 2;
     if (m * CW > 8 * JBS) {
         vi_set_error("vi_jacobi_vectors: N=%d too large", N);
@@ -480,4 +480,12 @@ int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sw
                        (const double2*)d_log, log_stride, d_nround, d_V);
     VI_HIP(hipGetLastError());
     return VI_OK;
+}
+
+int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
+{
+    // few systems: narrow column blocks spread one system over more CUs (latency); many systems: wide blocks
+    // re-read the rotation log fewer times (throughput)
+    if (B * ((N + 35) / 36) < c->n_cu / 2) return launch_vectors<12>(c, B, N, d_log, max_sweeps, d_nround, d_V);
+    return launch_vectors<36>(c, B, N, d_log, max_sweeps, d_nround, d_V);
 }

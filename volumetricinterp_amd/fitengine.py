@@ -171,6 +171,10 @@ class FitEngine(object):
         rec = np.ascontiguousarray(rec, dtype=np.int32)
         log10a = np.asarray(log10a, dtype=np.float64)
         B, N, T = len(rec), self.N, self.T
+        trace = os.environ.get('VINTERP_TRACE') == '1'
+        if trace:
+            import time
+            t_tr = time.perf_counter()
         is_int = log10a == np.floor(log10a)
         if not self.warm_enabled() or len(set(rec[~is_int].tolist())) != int((~is_int).sum()):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
@@ -223,6 +227,9 @@ class FitEngine(object):
         _lib.check(_lib.lib.vi_d2h(h, tmp.ctypes.data_as(_lib.VOIDP), dchi.ptr, tmp.nbytes), 'd2h')
         out = np.empty(B)
         out[order] = tmp
+        if trace:
+            print('[search round] B=%d cold=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
         self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw
