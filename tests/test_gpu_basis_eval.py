@@ -145,24 +145,26 @@ def test_estimate_vs_reference(tag):
 
 
 def test_eval_many_timesteps_and_ragged_sizes():
-    """T = 6 rows (one 4-tile + two single passes), Q not a multiple of the block size, vs the oracle."""
+    """T = 22 rows (one 16-tile + one 4-tile + two single passes), Q not a multiple of the block size, vs the oracle."""
     import oracle
     f, es = _estimate('k8l2')
     rng = np.random.default_rng(8)
     Q = 777
     lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
     C = np.concatenate([f['Coeffs'], f['Coeffs'][:2] * 0.5])            # (6, 32)
+    C = np.concatenate([C, -C, 3 * C, C[:4] + C[1:5]])                 # (22, 32)
     out = es.evaluate_coeffs(C, lat, lon, alt, check_hull=False)
     o = oracle.SphHarmLagOracle(maxk=8, maxl=2)
     A = o.basis(lat, lon, alt)
-    for t in range(6):
+    assert C.shape[0] == 22
+    for t in range(22):
         assert rel(out[t], A @ C[t]) <= 1e-10
     # hull mask vs the reference's per-point Qhull on a subset
     sub = slice(0, 120)
     outh = es.evaluate_coeffs(C[:1], lat[sub], lon[sub], alt[sub], check_hull=True)
     chk = oracle.check_hull(f['hull_vert'], lat[sub], lon[sub], alt[sub])
     assert np.array_equal(np.isfinite(outh[0]), chk)
-    assert es.evaluate_coeffs(C, lat[:0], lon[:0], alt[:0]).shape == (6, 0)
+    assert es.evaluate_coeffs(C, lat[:0], lon[:0], alt[:0]).shape == (22, 0)
 
 
 def test_rbf_estimate_vs_oracle():

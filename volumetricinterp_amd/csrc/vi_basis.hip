@@ -576,13 +576,23 @@ int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double
     auto shm = [&](int TT) { return (size_t)(((nj * L + 1) & ~1) + TT * N) * sizeof(double) + L * sizeof(int) + 16; };
     static bool attr = false;
     if (!attr) {
+        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
+    // timestep tiles of 16 / 4 / 1: the basis is recomputed once per tile, so a wide tile amortises it and the
+    // contraction (2N flop per point-timestep) dominates.  Measured at 128^3, N = 144: 1.4e10 / 3.9e10 / 6.2e10
+    // point-timesteps/s for tiles of 1 / 4 / 16 (a tile of 8 is slower than 16).  fp64 MFMA has the same peak as the
+    // fp64 VALU on gfx950 (78.6 TF), so a GEMM reformulation of the contraction would not raise the ceiling.
+    const bool wide_ok = shm(16) <= 60 * 1024;
     int64_t t = 0;
     while (t < T) {
-        if (T - t >= 4) {
+        if (wide_ok && T - t >= 16) {
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 16>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(16), m->ctx->stream,
+                               m->sph, Q, lat, lon, alt, 16, Cp + t * N, hull, F, tol, out + t * Q);
+            t += 16;
+        } else if (T - t >= 4) {
             hipLaunchKernelGGL((k_eval_sph_fast<L, K, 4>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 4, Cp + t * N, hull, F, tol, out + t * Q);
             t += 4;
