@@ -90,9 +90,11 @@ def main():
     from volumetricinterp_amd.models.sphharmlag import Model
 
     from volumetricinterp_amd.parallel import Comm
-    comm = Comm(backend='nccl' if world > 1 else None)      # "nccl" is RCCL on ROCm; no-op for one process
-
     ctx = _lib.get_context(local_rank)
+    # control plane over a Unix socket + ncclBroadcast (RCCL over xGMI) for the shared parameters; no torch in
+    # GPU processes (two HIP runtimes in one process crash).  VINTERP_DIST_BACKEND=socket skips RCCL, e.g. to
+    # rehearse several ranks on one GPU.
+    comm = Comm(backend=os.environ.get('VINTERP_DIST_BACKEND', 'rccl') if world > 1 else None, ctx=ctx)
     model = Model(io.StringIO(CFG), ctx=ctx)
     h = model.handle(ctx)
     N = model.nbasis
@@ -178,6 +180,7 @@ def main():
                              'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
                              'fit_outcome': res['search']['curvature']['outcomes']},
             'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
+            'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
             'roofline': {'kernel': 'k_eval_sph_fast<6,4,1>', 'bound': 'hbm',
                          'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -165,6 +165,16 @@ int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, co
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
                        double rcond, double* d_C, int32_t* d_rank);
 
+/* ---- multi-GPU: one broadcast of shared parameters over RCCL (xGMI) -----------------------------
+ * Records are independent (interpolate.py:511), so the fit/evaluate path has no collective; the caller shards
+ * records across one process per GPU.  The only exchange is this broadcast of the parameters every rank
+ * needs (beam geometry, regularisation matrices, hull facets).  Rank 0 obtains a 128-byte id, ships it over
+ * its own control channel, then every rank calls vi_rccl_init.  RCCL is dlopen'ed on first use. */
+int  vi_rccl_unique_id(char* out128);
+int  vi_rccl_init(vi_ctx* ctx, int nranks, int rank, const char* id128);
+int  vi_rccl_bcast_f64(vi_ctx* ctx, double* d_buf, int64_t count, int root);
+int  vi_rccl_destroy(vi_ctx* ctx);
+
 /* Diagnostic: eigenvalues (unsorted) of B symmetric N x N systems by the in-LDS Jacobi kernel that
  * vi_solve_trunc_f64 uses, and the sweeps each system needed.  d_X is rescaled in place. */
 int  vi_eigvals_f64(vi_ctx* ctx, int64_t B, int32_t N, double* d_X, double* d_lam, int32_t* d_sweeps);

@@ -29,7 +29,7 @@ WORKER = textwrap.dedent('''
     import numpy as np
     sys.path.insert(0, %r)
     from volumetricinterp_amd.parallel import Comm, shard_bounds
-    comm = Comm(backend='gloo')
+    comm = Comm(backend=os.environ.get('TEST_BACKEND', 'gloo'))
     rng = np.random.default_rng(1)
     T, P, N = 7, 11, 5
     shared = dict(lat=rng.uniform(70, 80, P), R=rng.standard_normal((N, N))) if comm.rank == 0 else {}
@@ -48,7 +48,11 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_gloo_equals_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('backend,world', [('gloo', 2), ('socket', 2), ('socket', 3)])
+def test_multi_rank_equals_single_process(tmp_path, backend, world):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % REPO)
     with socket.socket() as s:
@@ -56,9 +60,9 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
         port = s.getsockname()[1]
     out = str(tmp_path / 'out.npz')
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), TEST_BACKEND=backend, VINTERP_RDV_PATH=str(tmp_path / 'rdv.sock'))
         procs.append(subprocess.Popen([sys.executable, str(script), out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
@@ -73,4 +77,4 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     np.testing.assert_array_equal(got['lat'], lat)
     np.testing.assert_array_equal(got['R'], R)
     np.testing.assert_array_equal(got['full'], want)          # sharded result == single-process result, bit for bit
-    assert float(got['tmax']) == 2.0
+    assert float(got['tmax']) == float(world)

@@ -47,6 +47,7 @@ struct vi_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int n_cu = 256;
+    void* rccl_comm = nullptr;   // ncclComm_t, created by vi_rccl_init
 };
 
 int vi_ctx_workspace(vi_ctx* ctx, size_t bytes, void** out);

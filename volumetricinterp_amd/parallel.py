@@ -4,12 +4,24 @@ The reference's record loop (volumetricinterp/interpolate.py:511) carries no sta
 the fit shards embarrassingly over timesteps and the evaluation over (timestep, point-tile) pairs
 (SURVEY 8e).  There is NO collective on the data path; the only communication is one broadcast of the
 shared parameters (beam geometry, regularisation matrices, hull facets) from rank 0 before the work
-starts, and an optional gather of the coefficient rows to rank 0 for a single HDF5 writer.
+starts, a barrier / max-reduction around timed regions, and an optional gather of the coefficient rows to
+rank 0 for a single HDF5 writer.
 
-``torch.distributed`` is used purely as the transport (backend "nccl" is RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests); nothing here touches the compute path, which stays in libvinterp.so.
+Two transports:
+
+* ``backend='rccl'`` (GPU runs): a tiny control plane over a Unix-domain socket (rank 0 serves; ranks are
+  launched by ``torch.distributed.run`` on ONE node and read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT from
+  the environment) carries the RCCL unique id, barriers and scalar reductions; the parameter broadcast itself
+  is ``ncclBroadcast`` on device buffers through libvinterp.so (``vi_rccl_*``), i.e. RCCL over xGMI.  PyTorch
+  is deliberately NOT imported in GPU processes: its wheel bundles its own HIP runtime, and two HIP runtimes
+  in one process crash (observed: SIGSEGV when torch was imported after libvinterp.so).
+* ``backend='gloo'`` (CPU tests): ``torch.distributed`` with the gloo backend.
 """
 import os
+import pickle
+import socket
+import struct
+import time
 
 import numpy as np
 
@@ -27,90 +39,235 @@ def shard_bounds(T, rank, world):
     return lo, min(T, lo + per)
 
 
-class Comm(object):
-    """Thin wrapper over a torch.distributed process group (or a no-op for a single process)."""
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack('<Q', len(payload)) + payload)
 
-    def __init__(self, backend=None, device=None):
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(1 << 20, n - len(buf)))
+        if not chunk:
+            raise ConnectionError('control channel closed')
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class SocketGroup(object):
+    """Star-shaped control plane of the ranks of one node: rank 0 serves a Unix-domain socket."""
+
+    def __init__(self, rank, world, timeout=120.):
+        self.rank, self.world = rank, world
+        run = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+        port = os.environ.get('MASTER_PORT', '0')
+        self.path = os.environ.get('VINTERP_RDV_PATH', '/tmp/vinterp_rdv_%s_%s_%d.sock' % (port, run, os.getuid()))
+        self.peers = {}
+        if rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(self.path)
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                conn.settimeout(None)
+                (r,) = struct.unpack('<I', _recv_exact(conn, 4))
+                self.peers[r] = conn
+            srv.close()
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+        else:
+            t0 = time.time()
+            while True:
+                s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    s.connect(self.path)
+                    break
+                except OSError:
+                    s.close()
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError('rank %d could not reach rank 0 at %s' % (rank, self.path))
+                    time.sleep(0.05)
+            s.sendall(struct.pack('<I', rank))
+            self.sock = s
+
+    def allgather(self, payload):
+        """Every rank contributes bytes; every rank gets the list (rank order)."""
+        if self.rank == 0:
+            parts = [payload] + [None] * (self.world - 1)
+            for r, c in self.peers.items():
+                parts[r] = _recv_msg(c)
+            blob = pickle.dumps(parts)
+            for c in self.peers.values():
+                _send_msg(c, blob)
+            return parts
+        _send_msg(self.sock, payload)
+        return pickle.loads(_recv_msg(self.sock))
+
+    def bcast(self, payload):
+        """Rank 0's bytes to everyone."""
+        if self.rank == 0:
+            for c in self.peers.values():
+                _send_msg(c, payload)
+            return payload
+        return _recv_msg(self.sock)
+
+    def close(self):
+        if self.rank == 0:
+            for c in self.peers.values():
+                c.close()
+        else:
+            self.sock.close()
+
+
+class Comm(object):
+    """Process group of the run (a no-op for a single process)."""
+
+    def __init__(self, backend=None, ctx=None):
         self.rank, self.world, self.local_rank = env_rank()
+        self.backend = None
+        self.ctx = ctx                      # _lib.Context for RCCL broadcasts (backend 'rccl')
+        self.grp = None
         self.dist = None
-        self.device = device
-        if self.world > 1:
+        self.rccl_ready = False
+        self.notes = []
+        if self.world <= 1:
+            return
+        if backend is None:
+            backend = 'rccl' if ctx is not None else 'gloo'
+        self.backend = backend
+        if backend == 'gloo':
             import torch
             import torch.distributed as dist
             self.torch = torch
-            if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-            self.backend = backend
-            if backend == 'nccl':
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device('cuda', self.local_rank)
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world,
-                                        device_id=self.device)
-            else:
-                self.device = torch.device('cpu')
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend='gloo', rank=self.rank, world_size=self.world)
             self.dist = dist
+        elif backend in ('rccl', 'socket'):
+            self.grp = SocketGroup(self.rank, self.world)
+            if backend == 'rccl' and ctx is not None:
+                self._init_rccl()
+        else:
+            raise ValueError('unknown backend %r' % backend)
 
+    def _init_rccl(self):
+        import ctypes as C
+        from . import _lib
+        ok = True
+        ident = b''
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            ok = _lib.lib.vi_rccl_unique_id(buf) == 0
+            ident = buf.raw if ok else b''
+        ident = self.grp.bcast(ident)
+        if len(ident) == 128:
+            ok = _lib.lib.vi_rccl_init(self.ctx.handle, self.world, self.rank, ident) == 0
+        else:
+            ok = False
+        oks = self.grp.allgather(b'1' if ok else b'0')
+        self.rccl_ready = all(o == b'1' for o in oks)
+        if not self.rccl_ready:
+            err = _lib.lib.vi_last_error()
+            self.notes.append('RCCL unavailable (%s); shared parameters go over the control socket'
+                              % (err.decode('utf-8', 'replace') if err else 'unknown'))
+
+    # ------------------------------------------------------------------------------------------
     def broadcast_arrays(self, arrays, src=0):
-        """Broadcast a dict of float64 ndarrays (shapes known on every rank only through rank `src`).
+        """Broadcast a dict of float64 ndarrays from rank 0 (shapes known only there).
 
-        One flat buffer, one collective: ~0.3 MB at the default order - latency-bound on xGMI."""
-        if self.dist is None:
+        One flat buffer, one collective: ~0.2 MB at the default order - latency-bound on xGMI."""
+        if self.world <= 1:
             return arrays
-        torch, dist = self.torch, self.dist
-        if self.rank == src:
-            names = sorted(arrays)
-            meta = [(n, tuple(np.asarray(arrays[n]).shape)) for n in names]
+        if src != 0:
+            raise ValueError('only rank 0 can be the source')
+        if self.backend == 'gloo':
+            torch, dist = self.torch, self.dist
+            meta = [(n, tuple(np.asarray(arrays[n]).shape)) for n in sorted(arrays)] if self.rank == 0 else None
+            box = [meta]
+            dist.broadcast_object_list(box, src=0)
+            meta = box[0]
+            total = int(sum(int(np.prod(s, dtype=np.int64)) for _, s in meta))
+            flat = (np.concatenate([np.asarray(arrays[n], dtype=np.float64).ravel() for n, _ in meta])
+                    if self.rank == 0 and total else np.empty(total))
+            t = torch.from_numpy(flat)
+            dist.broadcast(t, src=0)
+            flat = t.numpy()
         else:
-            meta = None
-        box = [meta]
-        dist.broadcast_object_list(box, src=src)
-        meta = box[0]
-        total = int(sum(int(np.prod(s, dtype=np.int64)) for _, s in meta))
-        if self.rank == src:
-            flat = np.concatenate([np.asarray(arrays[n], dtype=np.float64).ravel() for n, _ in meta]) \
-                if total else np.zeros(0)
-        else:
-            flat = np.empty(total)
-        t = torch.from_numpy(flat).to(self.device)
-        dist.broadcast(t, src=src)
-        flat = t.cpu().numpy()
+            meta = [(n, tuple(np.asarray(arrays[n]).shape)) for n in sorted(arrays)] if self.rank == 0 else None
+            meta = pickle.loads(self.grp.bcast(pickle.dumps(meta)))
+            total = int(sum(int(np.prod(s, dtype=np.int64)) for _, s in meta))
+            flat = (np.concatenate([np.asarray(arrays[n], dtype=np.float64).ravel() for n, _ in meta])
+                    if self.rank == 0 and total else np.empty(total))
+            done = False
+            if self.rccl_ready and total:
+                from . import _lib
+                d = self.ctx.to_device(flat) if self.rank == 0 else self.ctx.empty((total,))
+                rc = _lib.lib.vi_rccl_bcast_f64(self.ctx.handle, d.ptr, total, 0)
+                oks = self.grp.allgather(b'1' if rc == 0 else b'0')
+                if all(o == b'1' for o in oks):
+                    flat = d.download()
+                    done = True
+                else:
+                    self.notes.append('ncclBroadcast failed; fell back to the control socket')
+            if not done:
+                flat = np.frombuffer(self.grp.bcast(flat.tobytes() if self.rank == 0 else b''), dtype=np.float64)
         out, o = {}, 0
         for n, s in meta:
             k = int(np.prod(s, dtype=np.int64))
-            out[n] = flat[o:o + k].reshape(s).copy()
+            out[n] = np.array(flat[o:o + k]).reshape(s)
             o += k
         return out
 
     def gather_rows(self, local, T):
         """Concatenate the per-rank row blocks (in rank order) on every rank; (T, ...) result."""
         local = np.ascontiguousarray(local, dtype=np.float64)
-        if self.dist is None:
+        if self.world <= 1:
             return local
-        torch, dist = self.torch, self.dist
-        per = -(-T // self.world)
-        pad = np.zeros((per,) + local.shape[1:])
-        pad[:local.shape[0]] = local
-        t = torch.from_numpy(pad).to(self.device)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(outs, t)
-        full = np.concatenate([o.cpu().numpy() for o in outs], axis=0)
-        return full[:T]
+        if self.backend == 'gloo':
+            torch, dist = self.torch, self.dist
+            per = -(-T // self.world)
+            pad = np.zeros((per,) + local.shape[1:])
+            pad[:local.shape[0]] = local
+            t = torch.from_numpy(pad)
+            outs = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(outs, t)
+            return np.concatenate([o.numpy() for o in outs], axis=0)[:T]
+        parts = self.grp.allgather(pickle.dumps(local))
+        return np.concatenate([pickle.loads(p) for p in parts], axis=0)[:T]
 
     def barrier(self):
-        if self.dist is not None:
+        if self.world <= 1:
+            return
+        if self.backend == 'gloo':
             self.dist.barrier()
-            if self.backend == 'nccl':
-                self.torch.cuda.synchronize()
+        else:
+            self.grp.allgather(b'')
 
     def max_over_ranks(self, x):
-        if self.dist is None:
+        if self.world <= 1:
             return float(x)
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        if self.backend == 'gloo':
+            t = self.torch.tensor([float(x)], dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return max(struct.unpack('<d', p)[0] for p in self.grp.allgather(struct.pack('<d', float(x))))
 
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+        if self.grp is not None:
+            if self.rccl_ready and self.ctx is not None:
+                from . import _lib
+                _lib.lib.vi_rccl_destroy(self.ctx.handle)
+            self.grp.close()
+            self.grp = None
