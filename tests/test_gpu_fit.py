@@ -203,3 +203,24 @@ def test_default_order_report(tmp_path, capsys):
     # tools/exp_chi2table.py and DESIGN.md "Parity at the default order".
     assert abs(res['chi_sq'][0] - f['chi_sq'][0]) <= 1e-3 * f['chi_sq'][0]
     assert abs(math.log10(res['reg_params'][0][reg]) - math.log10(f['alpha'][0])) <= 0.01
+
+
+def test_solver_fallback_outside_the_in_lds_range():
+    """N = 200 does not fit the in-LDS Jacobi kernel (161 KB > 160 KB LDS): vi_solve_trunc_f64 falls back to
+    rocSOLVER syevj on the rescaled system - same truncation semantics, with and without pinv."""
+    rng = np.random.default_rng(3)
+    B, N = 3, 200
+    X, Y = [], []
+    for i in range(B):
+        A = rng.standard_normal((3 * N, N))
+        M = (A.T @ A) * 1e-19 + 10.0**(-21 - i) * np.diag(rng.standard_normal(N))
+        X.append(0.5 * (M + M.T))
+        Y.append(rng.standard_normal(N) * 1e-8)
+    X, Y = np.array(X), np.array(Y)
+    C, rank, H = solve_direct(X.copy(), Y, want_H=True)
+    C2, rank2, _ = solve_direct(X.copy(), Y, want_H=False)
+    for i in range(B):
+        ref = scipy.linalg.lstsq(X[i], Y[i])[0]
+        assert rank[i] == rank2[i] == N
+        assert rel(C[i], ref) <= 1e-9 and rel(C2[i], ref) <= 1e-9
+        assert rel(H[i], scipy.linalg.pinv(X[i])) <= 1e-9

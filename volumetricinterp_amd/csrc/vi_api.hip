@@ -188,6 +188,8 @@ extern "C" void vi_model_destroy(vi_model* m)
     (void)hipStreamSynchronize(m->ctx->stream);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->d_coef) (void)hipFree(m->d_coef);
+    if (m->d_hull) (void)hipFree(m->d_hull);
+    if (m->d_mask) (void)hipFree(m->d_mask);
     delete m;
 }
 

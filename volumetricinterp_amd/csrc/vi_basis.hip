@@ -238,21 +238,79 @@ struct EvalSink {
     }
 };
 
-__device__ __forceinline__ bool inside_hull(const double* __restrict__ eq, int F, double tol, double X, double Y, double Z)
+// Convex-hull test (estimate.py:153-178 semantics: inside <=> max_f (n_f . x + d_f) <= tol), as a mask pass.
+// `hull` is the internal buffer built by k_prep_hull: [c0 (3 doubles, 1 pad)] [F x 4 fp64 facet equations]
+// [F x float4 facets relative to c0].  With ~460 facets an fp64 test inside the evaluation kernel cost twice the
+// whole basis (dependent scalar loads), so the test is its own pass: the fp32 facets are staged in LDS once per
+// workgroup and evaluated relative to a reference point on the hull (fp32 error < 0.5 m for a hull of
+// ~1000 km); only lanes within HULL_BAND metres of the surface repeat the test in fp64.  The byte mask is
+// reused by every timestep tile of the evaluation.
+constexpr float HULL_BAND = 4.0f;
+
+__global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __restrict__ lat,
+                                                     const double* __restrict__ lon, const double* __restrict__ alt,
+                                                     const double* __restrict__ hull, int F, double tol,
+                                                     unsigned char* __restrict__ mask)
 {
-    bool in = true;
-    for (int f = 0; f < F; ++f) {
-        const double d = fma(eq[4 * f], X, fma(eq[4 * f + 1], Y, fma(eq[4 * f + 2], Z, eq[4 * f + 3])));
-        in = in && (d <= tol);
+    extern __shared__ __align__(16) float4 shpl[];
+    const float4* __restrict__ pl = reinterpret_cast<const float4*>(hull + 4 + 4 * (size_t)F);
+    for (int f = threadIdx.x; f < F; f += BLOCK) shpl[f] = pl[f];
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t qc = q < Q ? q : Q - 1;
+    double X, Y, Z;
+    geodetic2ecef(lat[qc], lon[qc], alt[qc], X, Y, Z);
+    const float dx = (float)(X - hull[0]), dy = (float)(Y - hull[1]), dz = (float)(Z - hull[2]);
+    float dmax = -3.0e38f;
+    int f = 0;
+    for (; f + 8 <= F; f += 8) {
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 p = shpl[f + u];
+            d[u] = fmaf(p.x, dx, fmaf(p.y, dy, fmaf(p.z, dz, p.w)));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dmax = fmaxf(dmax, d[u]);
     }
-    return in;
+    for (; f < F; ++f) {
+        const float4 p = shpl[f];
+        dmax = fmaxf(dmax, fmaf(p.x, dx, fmaf(p.y, dy, fmaf(p.z, dz, p.w))));
+    }
+    bool in;
+    if (dmax > (float)tol + HULL_BAND) in = false;
+    else if (dmax < (float)tol - HULL_BAND) in = true;
+    else {                                                               // borderline: exact fp64 test
+        const double* __restrict__ eq = hull + 4;
+        in = true;
+        for (int g = 0; g < F; ++g) {
+            const double d = fma(eq[4 * g], X, fma(eq[4 * g + 1], Y, fma(eq[4 * g + 2], Z, eq[4 * g + 3])));
+            in = in && (d <= tol);
+        }
+    }
+    if (q < Q) mask[q] = in ? 1 : 0;
+}
+
+// hullbuf <- [c0][eq][float4 facets]; c0 = foot of the origin's perpendicular on facet 0 (a point of the hull surface)
+__global__ void k_prep_hull(int F, const double* __restrict__ eq, double* __restrict__ hullbuf)
+{
+    const double c0x = -eq[3] * eq[0], c0y = -eq[3] * eq[1], c0z = -eq[3] * eq[2];
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hullbuf[0] = c0x; hullbuf[1] = c0y; hullbuf[2] = c0z; hullbuf[3] = 0.0;
+    }
+    float4* pl = reinterpret_cast<float4*>(hullbuf + 4 + 4 * (size_t)F);
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+        const double nx = eq[4 * f], ny = eq[4 * f + 1], nz = eq[4 * f + 2], off = eq[4 * f + 3];
+        hullbuf[4 + 4 * f] = nx; hullbuf[4 + 4 * f + 1] = ny; hullbuf[4 + 4 * f + 2] = nz; hullbuf[4 + 4 * f + 3] = off;
+        pl[f] = make_float4((float)nx, (float)ny, (float)nz, (float)(nx * c0x + ny * c0y + nz * c0z + off));
+    }
 }
 
 template <int LCAP, int KCAP, int TT>
 __global__ __launch_bounds__(BLOCK) void k_eval_sph(SphDev M, int64_t Q, const double* __restrict__ lat,
                                                     const double* __restrict__ lon, const double* __restrict__ alt,
                                                     int tcount, const double* __restrict__ Cp,
-                                                    const double* __restrict__ hull, int F, double tol,
+                                                    const unsigned char* __restrict__ mask, int F, double tol,
                                                     double* __restrict__ out)
 {
     const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -260,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph(SphDev M, int64_t Q, const d
     const Geom g = sph_geom(M, lat[qc], lon[qc], alt[qc]);
     bool in = true;
     if (F > 0) {
-        in = inside_hull(hull, F, tol, g.X, g.Y, g.Z);
+        in = mask[qc] != 0;
         if (!__any(in && q < Q)) {            // whole wave outside the hull: skip the basis work
             if (q < Q)
                 for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
@@ -360,7 +418,7 @@ template <int L, int K, int TT>
 __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, const double* __restrict__ lat,
                                                          const double* __restrict__ lon, const double* __restrict__ alt,
                                                          int tcount, const double* __restrict__ Cp,
-                                                         const double* __restrict__ hull, int F, double tol,
+                                                         const unsigned char* __restrict__ mask, int F, double tol,
                                                          double* __restrict__ out)
 {
     extern __shared__ __align__(16) double sh[];
@@ -383,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, co
     const Geom g = sph_geom(M, lat[qc], lon[qc], alt[qc]);
     bool in = true;
     if (F > 0) {
-        in = inside_hull(hull, F, tol, g.X, g.Y, g.Z);
+        in = mask[qc] != 0;
         if (!__any(in && q < Q)) {
             if (q < Q)
                 for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
@@ -489,7 +547,7 @@ template <int TT>
 __global__ __launch_bounds__(BLOCK) void k_eval_rbf(RbfDev M, int64_t Q, const double* __restrict__ lat,
                                                     const double* __restrict__ lon, const double* __restrict__ alt,
                                                     int tcount, const double* __restrict__ C,
-                                                    const double* __restrict__ hull, int F, double tol,
+                                                    const unsigned char* __restrict__ mask, int F, double tol,
                                                     double* __restrict__ out)
 {
     const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -498,7 +556,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_rbf(RbfDev M, int64_t Q, const d
     geodetic2ecef(lat[qc], lon[qc], alt[qc], X, Y, Z);
     bool in = true;
     if (F > 0) {
-        in = inside_hull(hull, F, tol, X, Y, Z);
+        in = mask[qc] != 0;
         if (!__any(in && q < Q)) {
             if (q < Q)
                 for (int t = 0; t < tcount; ++t) out[(int64_t)t * Q + q] = __builtin_nan("");
@@ -546,7 +604,7 @@ int launch_basis_sph(vi_model* m, int64_t P, const double* lat, const double* lo
 
 template <int LCAP, int KCAP>
 int launch_eval_sph(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
-                    const double* Cp, const double* hull, int F, double tol, double* out)
+                    const double* Cp, const unsigned char* hull, int F, double tol, double* out)
 {
     const int N = m->N;
     int64_t t = 0;
@@ -569,7 +627,7 @@ int launch_eval_sph(vi_model* m, int64_t Q, const double* lat, const double* lon
 
 template <int L, int K>
 int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
-                         const double* Cp, const double* hull, int F, double tol, double* out)
+                         const double* Cp, const unsigned char* hull, int F, double tol, double* out)
 {
     const int N = m->N;
     const int nj = m->nvmax0 + 1;
@@ -666,6 +724,31 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
     if (Q == 0 || T == 0) return VI_OK;
     VI_HIP(hipSetDevice(m->ctx->device));
     const int N = m->N;
+    if (F > 0) {
+        const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + (size_t)F * sizeof(float4) + 64;
+        if (need > m->hull_bytes) {
+            VI_HIP(hipStreamSynchronize(m->ctx->stream));
+            if (m->d_hull) VI_HIP(hipFree(m->d_hull));
+            m->d_hull = nullptr;
+            m->hull_bytes = 0;
+            VI_HIP(hipMalloc((void**)&m->d_hull, need));
+            m->hull_bytes = need;
+        }
+        hipLaunchKernelGGL(k_prep_hull, dim3(4), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
+        VI_HIP(hipGetLastError());
+        if ((size_t)Q > m->mask_bytes) {
+            VI_HIP(hipStreamSynchronize(m->ctx->stream));
+            if (m->d_mask) VI_HIP(hipFree(m->d_mask));
+            m->d_mask = nullptr;
+            m->mask_bytes = 0;
+            VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
+            m->mask_bytes = (size_t)Q;
+        }
+        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
+                           d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
+        VI_HIP(hipGetLastError());
+    }
+    const unsigned char* d_mask = F > 0 ? m->d_mask : nullptr;
     if (m->kind == VI_MODEL_SPHHARMLAG) {
         const size_t need = (size_t)T * N * sizeof(double);
         if (need > m->coef_bytes) {
@@ -682,7 +765,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         const int L = m->sph.maxl, K = m->sph.maxk;
         if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
 #define VI_FAST(LL, KK) \
-    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out)
+    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out)
             VI_FAST(6, 4);
             VI_FAST(2, 8);
             VI_FAST(3, 4);
@@ -693,11 +776,11 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
 #undef VI_FAST
         }
         if (L <= 6 && K <= 4)
-            return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+            return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
         if (L <= 12 && K <= 8)
-            return launch_eval_sph<12, 8>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+            return launch_eval_sph<12, 8>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
         if (L <= 24 && K <= 16)
-            return launch_eval_sph<24, 16>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_hull_eq, F, hull_tol, d_out);
+            return launch_eval_sph<24, 16>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
         vi_set_error("vi_eval_f64: order MAXL=%d MAXK=%d beyond the compiled limits (24, 16)", L, K);
         return VI_ERR_UNSUPPORTED;
     }
@@ -706,10 +789,10 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         const int tc = (int)((T - t) >= 4 ? 4 : (T - t));
         if (tc == 4)
             hipLaunchKernelGGL(k_eval_rbf<4>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
-                               d_lon, d_alt, tc, d_C + t * N, d_hull_eq, F, hull_tol, d_out + t * Q);
+                               d_lon, d_alt, tc, d_C + t * N, d_mask, F, hull_tol, d_out + t * Q);
         else
             hipLaunchKernelGGL(k_eval_rbf<1>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
-                               d_lon, d_alt, 1, d_C + t * N, d_hull_eq, F, hull_tol, d_out + t * Q);
+                               d_lon, d_alt, 1, d_C + t * N, d_mask, F, hull_tol, d_out + t * Q);
         VI_HIP(hipGetLastError());
         t += (tc == 4) ? 4 : 1;
     }

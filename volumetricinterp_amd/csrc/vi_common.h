@@ -86,4 +86,8 @@ struct vi_model {
     std::vector<void*> allocs;   // device allocations owned by the model
     double* d_coef = nullptr;    // reordered + scaled coefficient staging for vi_eval (grow-only)
     size_t coef_bytes = 0;
+    double* d_hull = nullptr;    // internal hull buffer of vi_eval (fp64 facets + fp32 prefilter), grow-only
+    size_t hull_bytes = 0;
+    unsigned char* d_mask = nullptr;   // inside-hull byte mask of the last vi_eval grid, grow-only
+    size_t mask_bytes = 0;
 };
