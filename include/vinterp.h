@@ -165,6 +165,14 @@ int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, co
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
                        double rcond, double* d_C, int32_t* d_rank);
 
+/* ---- generalised cross validation: replaces the loop of Interpolate.gcvobjfunct (interpolate.py:332-351) ----
+ * For ONE record (d_AWA N x N, d_y N, d_W / d_b P) and one alpha: res[i] = W_p (a_p . C_(-p) - b_p)^2 for the np
+ * data points p = pidx[i], where C_(-p) is the regularised truncated solution of the fit that leaves point p
+ * out - a rank-one down-date of the normal equations, np eigen-solves in one batch.  Synchronous. */
+int  vi_gcv_terms_f64(vi_ctx* ctx, int64_t np, int64_t P, int32_t N, const double* d_At, const int32_t* d_pidx,
+                      const double* d_AWA, const double* d_y, const double* d_W, const double* d_b,
+                      double alpha, const double* d_R, double rcond, double* d_res);
+
 /* ---- multi-GPU: one broadcast of shared parameters over RCCL (xGMI) -----------------------------
  * Records are independent (interpolate.py:511), so the fit/evaluate path has no collective; the caller shards
  * records across one process per GPU.  The only exchange is this broadcast of the parameters every rank

@@ -22,5 +22,5 @@ from .geodesy import geodetic2ecef            # noqa: F401
 from .sphharmlag import SphHarmLagOracle      # noqa: F401
 from .radbasfun import RadBasFunOracle        # noqa: F401
 from .fit import (eval_C, chi2objfunct, chi2_search, find_reg_param,   # noqa: F401
-                  fit_records, compute_hull_vertices)
+                  fit_records, compute_hull_vertices, gcvobjfunct, gcv_search)
 from .evaluate import get_C, check_hull, evaluate                      # noqa: F401

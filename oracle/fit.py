@@ -80,12 +80,42 @@ def chi2_search(A, b, W, reg_matrices, reg, regularization_list, counter=None, t
     return np.power(10., solution)
 
 
-def find_reg_param(A, b, W, reg_matrices, regularization_list, counter=None, traces=None):
-    """interpolate.py:97-147 with method 'chi2' (the default, :135-136)."""
+def gcvobjfunct(alpha, A0, b0, W0, reg_matrices, reg, regularization_list, counter=None):
+    """interpolate.py:299-351: leave-one-out sum of squared weighted residuals at 10**alpha."""
+    alpha = float(np.squeeze(alpha))
+    reg_params = {rl: (np.power(10., alpha) if rl == reg else 0.) for rl in regularization_list}
+    residuals = []
+    for i in range(len(b0)):
+        Ai, bi, Wi = A0[i, :], b0[i], W0[i]
+        A = np.delete(A0, i, 0)
+        b = np.delete(b0, i, 0)
+        W = np.delete(W0, i, 0)
+        C = eval_C(A, b, W, reg_matrices, reg_params, regularization_list)
+        if counter is not None:
+            counter[0] += 1
+        val = np.squeeze(np.dot(Ai, C))
+        residuals.append((val - bi)**2 * Wi)
+    return sum(residuals)
+
+
+def gcv_search(A, b, W, reg_matrices, reg, regularization_list, counter=None):
+    """interpolate.py:263-297: Nelder-Mead from alpha0 = -20."""
+    sol = scipy.optimize.minimize(gcvobjfunct, -20., args=(A, b, W, reg_matrices, reg, regularization_list, counter),
+                                  method='Nelder-Mead')
+    if not sol.success:
+        raise ValueError('Minima of GCV function could not be found')
+    return np.power(10., sol.x[0])
+
+
+def find_reg_param(A, b, W, reg_matrices, regularization_list, counter=None, traces=None, method='chi2'):
+    """interpolate.py:97-147; method 'chi2' is the default (:135-136), 'gcv' the other working one."""
     out = {}
     for rl in regularization_list:
         tr = {} if traces is not None else None
         try:
+            if method == 'gcv':
+                out[rl] = gcv_search(A, b, W, reg_matrices, rl, regularization_list, counter)
+                continue
             out[rl] = chi2_search(A, b, W, reg_matrices, rl, regularization_list, counter, tr)
         except ValueError:
             out[rl] = np.nan
@@ -101,7 +131,7 @@ def compute_hull_vertices(lat, lon, alt):
     return R[ConvexHull(R).vertices]
 
 
-def fit_records(model, lat, lon, alt, value, error, reg_matrices, regularization_list, counter=None):
+def fit_records(model, lat, lon, alt, value, error, reg_matrices, regularization_list, counter=None, method='chi2'):
     """Record loop of calc_coeffs, interpolate.py:511-579 (no file I/O).
 
     value, error: (T, P).  Returns Coeffs (T,N), Covariance (T,N,N), chi_sq (T,),
@@ -117,7 +147,7 @@ def fit_records(model, lat, lon, alt, value, error, reg_matrices, regularization
         W = np.array(er0**(-2))
         b = ne0
         A = model.basis(lat0, lon0, alt0)
-        reg_params = find_reg_param(A, b, W, reg_matrices, regularization_list, counter)
+        reg_params = find_reg_param(A, b, W, reg_matrices, regularization_list, counter, method=method)
         params.append(reg_params)
         if np.any(np.isnan([v for v in reg_params.values()])):
             Coeffs.append(np.full(N, np.nan))

@@ -160,7 +160,7 @@ def test_public_eval_C_and_find_reg_param(tmp_path):
         it.eval_C(A, b * np.nan, W, regm, {reg: 1e-20})
     assert np.isnan(it.find_reg_param(A, b, W * np.inf, regm)[reg])
     with pytest.raises(NotImplementedError):
-        it.find_reg_param(A, b, W, regm, method='gcv')
+        it.find_reg_param(A, b, W, regm, method='manual')
 
 
 def test_rbf_fit_no_regularisation(tmp_path):
@@ -224,3 +224,28 @@ def test_solver_fallback_outside_the_in_lds_range():
         assert rank[i] == rank2[i] == N
         assert rel(C[i], ref) <= 1e-9 and rel(C2[i], ref) <= 1e-9
         assert rel(H[i], scipy.linalg.pinv(X[i])) <= 1e-9
+
+
+def test_gcv_on_gpu_matches_reference(tmp_path):
+    """REGULARIZATION_METHOD = gcv: leave-one-out objective as batched rank-one down-dated solves on the device,
+    Nelder-Mead on the host (the reference's own scipy call)."""
+    f = load_golden('fit_gcv')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    assert it.reg_method == 'gcv'
+    # stage: objective values at the alphas the reference evaluated (record 0)
+    import oracle
+    o = oracle.SphHarmLagOracle.from_config(io.StringIO(str(f['cfg'])))
+    A = o.basis(f['lat'], f['lon'], f['alt'])
+    W = f['error'][0]**-2
+    for a, v in f['gcv_calls'][:4]:
+        got = it.gcvobjfunct(a, A, f['value'][0], W, regm, reg)
+        assert abs(got - v) <= 1e-6 * abs(v), (a, got, v)
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    for t in range(2):
+        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-4
+        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 1e-4
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-4 * f['chi_sq'][t]
+    assert abs(math.log10(it.gcv(A, f['value'][0], W, regm, reg)) - math.log10(f['alpha'][0])) <= 1e-4
+    assert abs(math.log10(it.find_reg_param(A, f['value'][0], W, regm, method='gcv')[reg])
+               - math.log10(f['alpha'][0])) <= 1e-4

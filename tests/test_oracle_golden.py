@@ -166,3 +166,21 @@ def test_evaluate_matches_reference():
         with pytest.raises(ValueError, match='Requested time out of range of data file.'):
             oracle.get_C(t_mid - dt.timedelta(seconds=4000), f['utime'], f['Coeffs'], f['Covariance'])
         assert str(e[tag + '_oor']) == 'Requested time out of range of data file.'
+
+
+def test_gcv_matches_reference():
+    """Generalised cross validation (interpolate.py:263-351): objective values and the Nelder-Mead minimum."""
+    f = load_golden('fit_gcv')
+    model, reglist, regm = _fit_from_fixture(f)
+    A = model.basis(f['lat'], f['lon'], f['alt'])
+    W = f['error'][0]**-2
+    for a, v in f['gcv_calls'][:3]:
+        got = oracle.gcvobjfunct(a, A, f['value'][0], W, regm, 'curvature', reglist)
+        assert abs(got - v) <= 1e-8 * abs(v)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        C, dC, c2, params = oracle.fit_records(model, f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm, reglist,
+                                               method='gcv')
+    for t in range(2):
+        assert abs(np.log10(params[t]['curvature']) - np.log10(f['alpha'][t])) <= 1e-6
+        assert rel(C[t], f['Coeffs'][t]) <= 1e-5

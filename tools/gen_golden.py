@@ -314,6 +314,49 @@ def gen_fit(workdir):
          self_noise=np.array([rel(it2.Coeffs[t], it.Coeffs[t]) for t in range(2)]))
 
 
+def gen_gcv(workdir):
+    """Generalised cross validation (interpolate.py:263-351) on the well-conditioned MAXK=8, MAXL=2 model."""
+    regs = np.load(os.path.join(GOLD, 'regmat.npz'))
+    R = regs['k8l2_curvature']
+    cfg = config_text(reglist='curvature', maxk=8, maxl=2, cap=10).replace('REGULARIZATION_METHOD = chi2',
+                                                                           'REGULARIZATION_METHOD = gcv')
+    m = ref_model(cfg)
+    nb, nr = 6, 30                                            # 180 points: 180 leave-one-out fits per objective call
+    lat, lon, alt = synth.beams(nb, nr, seed=3)
+    A = m.basis(lat, lon, alt)
+    value, error = synth.synth_records(A, 2, seed0=4000)
+    value[1, 11] = np.nan
+    utime = synth.unix_times(2)
+    it = ref_interpolate(cfg, workdir)
+    it.read_datafile = lambda fn: (utime, lat, lon, alt, value.copy(), error.copy())
+    it.model.eval_reg_matricies['curvature'] = lambda: R
+    calls = []
+    og = it.gcvobjfunct
+
+    def logged(alpha, *a):
+        v = og(alpha, *a)
+        calls.append((float(np.squeeze(alpha)), float(v)))
+        return v
+    it.gcvobjfunct = logged
+    params = []
+    ofr = it.find_reg_param
+
+    def frp(*a, **k):
+        r = ofr(*a, **k)
+        params.append(dict(r))
+        return r
+    it.find_reg_param = frp
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        it.calc_coeffs()
+    alphas = [p['curvature'] for p in params]
+    print('gcv alphas', alphas, 'objective calls', len(calls), 'chi_sq', it.chi_sq)
+    save('fit_gcv', cfg=np.array(cfg), reg=np.array('curvature'), R=R, lat=lat, lon=lon, alt=alt, utime=utime,
+         value=value, error=error, Coeffs=it.Coeffs, Covariance=it.Covariance, chi_sq=it.chi_sq,
+         hull_vert=it.hull_vert, alpha=np.array(alphas, dtype=np.float64), gcv_calls=np.array(calls))
+
+
 def gen_eval(workdir):
     from volumetricinterp.estimate import Estimate
     out = {}
@@ -355,7 +398,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     setup_reference(args.ref)
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
-    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('eval', gen_eval)]
+    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('eval', gen_eval)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue

@@ -102,6 +102,48 @@ __global__ void k_v_vec(int N, const double* __restrict__ V, const int* __restri
     }
 }
 
+// Leave-one-out systems of generalised cross validation (interpolate.py:333-349): deleting data point p from a
+// record is a rank-one down-date of its normal equations,
+//   X_p = AWA - W_p a_p a_p^T + alpha R,   y_p = y - W_p b_p a_p,      a_p = column p of the N x P basis.
+__global__ void k_form_loo(int N, int64_t P, const double* __restrict__ At, const int* __restrict__ pidx,
+                           const double* __restrict__ AWA, const double* __restrict__ yv, const double* __restrict__ W,
+                           const double* __restrict__ b, double alpha, const double* __restrict__ R,
+                           double* __restrict__ X, double* __restrict__ yl)
+{
+    extern __shared__ double sha[];            // a_p [N]
+    const int64_t i = blockIdx.x;
+    const int64_t p = pidx[i];
+    for (int n = threadIdx.x; n < N; n += blockDim.x) sha[n] = At[(int64_t)n * P + p];
+    __syncthreads();
+    const double w = W[p], bw = W[p] * b[p];
+    const int NN = N * N;
+    for (int e = threadIdx.x; e < NN; e += blockDim.x) {
+        const int r = e / N, c = e - r * N;
+        double v = fma(-w * sha[r], sha[c], AWA[e]);
+        if (R) v = fma(alpha, R[e], v);
+        X[i * NN + e] = v;
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) yl[i * N + n] = fma(-bw, sha[n], yv[n]);
+}
+
+// res[i] = (a_p . C_i - b_p)^2 W_p
+__global__ void k_loo_resid(int64_t n, int N, int64_t P, const double* __restrict__ At, const int* __restrict__ pidx,
+                            const double* __restrict__ C, const double* __restrict__ W, const double* __restrict__ b,
+                            double* __restrict__ res)
+{
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int64_t p = pidx[i];
+    double acc = 0.0;
+    for (int n = lane; n < N; n += 64) acc = fma(At[(int64_t)n * P + p], C[i * N + n], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) {
+        const double d = acc - b[p];
+        res[i] = d * d * W[p];
+    }
+}
+
 // rocSOLVER's syevd loses accuracy on matrices of tiny magnitude (A^T W A entries are ~1e-19 because
 // W = sigma^-2 ~ 1e-22): measured rel(C) 0.6 on the raw system vs 2e-8 once it is scaled.  Scale every
 // system by an exact power of two to max|X| in [1, 2); eigenvalues are scaled back in k_trunc_apply.
@@ -573,4 +615,44 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
         VI_HIP(hipGetLastError());
     }
     return VI_OK;
+}
+
+// ---- generalised cross validation objective (interpolate.py:299-351) -----------------------------------
+// For one record (normal equations d_AWA (N x N), d_y (N), weights / data d_W, d_b (P)) and one alpha: the sum
+// over the np listed data points of the squared, weighted residual of each point against the fit that leaves it
+// out.  np truncated eigen-solves in one batch.  d_res receives the np individual terms.
+extern "C" int vi_gcv_terms_f64(vi_ctx* c, int64_t np, int64_t P, int32_t N, const double* d_At, const int32_t* d_pidx,
+                                const double* d_AWA, const double* d_y, const double* d_W, const double* d_b,
+                                double alpha, const double* d_R, double rcond, double* d_res)
+{
+    VI_REQUIRE(c && d_At && d_pidx && d_AWA && d_y && d_W && d_b && d_res, "null argument");
+    VI_REQUIRE(np >= 0 && P > 0 && N > 0, "bad size");
+    if (np == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    // systems are formed and solved in chunks; X / y / C live in a private allocation because
+    // vi_solve_trunc_f64 uses the context workspace itself
+    int64_t Bc = (int64_t)(((size_t)1 << 30) / ((size_t)NN * sizeof(double)));
+    if (Bc < 1) Bc = 1;
+    if (Bc > np) Bc = np;
+    double* buf = nullptr;
+    VI_HIP(hipMalloc((void**)&buf, (size_t)Bc * (NN + 2 * (size_t)N) * sizeof(double)));
+    double* X = buf;
+    double* yl = X + (size_t)Bc * NN;
+    double* Cl = yl + (size_t)Bc * N;
+    int rc = VI_OK;
+    for (int64_t i0 = 0; i0 < np && rc == VI_OK; i0 += Bc) {
+        const int64_t bc = (np - i0) < Bc ? (np - i0) : Bc;
+        hipLaunchKernelGGL(k_form_loo, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, P, d_At,
+                           d_pidx + i0, d_AWA, d_y, d_W, d_b, alpha, d_R, X, yl);
+        if (hipGetLastError() != hipSuccess) { vi_set_error("k_form_loo launch failed"); rc = VI_ERR_HIP; break; }
+        rc = vi_solve_trunc_f64(c, bc, N, X, yl, nullptr, rcond, Cl, nullptr, 0.0, nullptr);
+        if (rc != VI_OK) break;
+        hipLaunchKernelGGL(k_loo_resid, dim3((unsigned)((bc + 3) / 4)), dim3(256), 0, c->stream, bc, N, P, d_At, d_pidx + i0,
+                           Cl, d_W, d_b, d_res + i0);
+        if (hipGetLastError() != hipSuccess) { vi_set_error("k_loo_resid launch failed"); rc = VI_ERR_HIP; }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    return rc;
 }

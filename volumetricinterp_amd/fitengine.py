@@ -36,8 +36,10 @@ _lib._sig('vi_warm_prepare_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib
           _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, C.c_double, _lib.VOIDP)
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -276,6 +278,49 @@ class FitEngine(object):
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
         return params, infos
 
+    # ---- generalised cross validation (interpolate.py:263-351) ------------------------------------------
+    def gcv_objective(self, t, log10a, name, pidx):
+        """Interpolate.gcvobjfunct for record t: sum over the listed points of the leave-one-out residuals."""
+        pidx = np.ascontiguousarray(pidx, dtype=np.int32)
+        npnt, N, P = len(pidx), self.N, self.P
+        dp = self._buf('g_pidx', (npnt,), np.int32).upload(pidx)
+        dres = self._buf('g_res', (npnt,))
+        alpha = float(np.power(10., float(np.squeeze(log10a))))
+        _lib.check(_lib.lib.vi_gcv_terms_f64(self.ctx.handle, npnt, P, N, self.At.ptr, dp.ptr,
+                                             self.dAWA.offset_ptr(t * N * N), self.dy.offset_ptr(t * N),
+                                             self.dW.offset_ptr(t * P), self.db.offset_ptr(t * P), alpha,
+                                             self.R[name].ptr, EPS, dres.ptr), 'vi_gcv_terms_f64')
+        res = np.empty(npnt)
+        _lib.check(_lib.lib.vi_d2h(self.ctx.handle, res.ctypes.data_as(_lib.VOIDP), dres.ptr, res.nbytes), 'd2h')
+        self.stats['solves'] += npnt
+        self.stats['launches'] += 1
+        return sum(res.tolist())                    # the reference's left-to-right Python sum
+
+    def search_gcv(self, point_lists):
+        """find_reg_param with method 'gcv' for every loaded record: Nelder-Mead from log10(alpha) = -20
+        (scipy.optimize.minimize, exactly the reference's call at interpolate.py:291) on the device objective.
+        point_lists[t]: indices of the finite data points of record t, or None to skip (NaN)."""
+        import scipy.optimize
+        params = [dict() for _ in range(self.T)]
+        infos = {}
+        for name in self.regularization_list:
+            outcomes = []
+            for t in range(self.T):
+                if point_lists[t] is None:
+                    params[t][name] = float('nan')
+                    outcomes.append('skipped')
+                    continue
+                sol = scipy.optimize.minimize(lambda a, _t=t: self.gcv_objective(_t, a, name, point_lists[_t]), -20.,
+                                              method='Nelder-Mead')
+                if sol.success:
+                    params[t][name] = float(np.power(10., sol.x[0]))
+                    outcomes.append('minimum')
+                else:                               # ValueError('Minima of GCV function could not be found') -> NaN
+                    params[t][name] = float('nan')
+                    outcomes.append('no_minimum')
+            infos[name] = dict(outcomes=outcomes)
+        return params, infos
+
     def finalize(self, params, calccov=True):
         """Final eval_C(calccov=True) + chi^2 for every record (interpolate.py:566-569).
 
@@ -324,8 +369,12 @@ class FitEngine(object):
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
-    def fit(self, W, b, npts, calccov=True, prefetch=None, multisection=None):
+    def fit(self, W, b, npts, calccov=True, prefetch=None, multisection=None, method='chi2', point_lists=None):
         self.load_records(W, b)
+        if method == 'gcv':
+            params, infos = self.search_gcv(point_lists)
+            Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+            return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
         params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)

@@ -57,12 +57,12 @@ class Interpolate(object):
     def _check_method(self, method):
         if method is None:
             method = 'chi2'                    # interpolate.py:135-136
-        if method == 'chi2':
+        if method in ('chi2', 'gcv'):
             return method
-        if method in ('gcv', 'manual', 'prompt'):
-            # gcv: SURVEY 8f row N3 (not built yet); manual/prompt raise TypeError in the reference (F10)
-            raise NotImplementedError("regularisation method %r is not available in volumetricinterp_amd "
-                                      "(only 'chi2', the reference default)" % method)
+        if method in ('manual', 'prompt'):
+            # both raise TypeError in the reference itself (8-argument signatures called with 5)
+            raise NotImplementedError("regularisation method %r is broken in the reference and not provided by "
+                                      "volumetricinterp_amd ('chi2' and 'gcv' are)" % method)
         raise KeyError(method)
 
     def _engine_for(self, A, reg_matrices):
@@ -87,14 +87,17 @@ class Interpolate(object):
             print(err)
             print('Returning NANs for regularization parameters.')
             return {rl: np.nan for rl in self.regularization_list}
-        try:
-            eng.load_records(W[None, :], b[None, :])
+        eng.load_records(W[None, :], b[None, :])
+        if method == 'gcv':
+            params, infos = eng.search_gcv([np.arange(len(b), dtype=np.int32)])
+        else:
             params, infos = eng.search([len(b)])
-        finally:
-            pass
         for rl in self.regularization_list:
             reg_params[rl] = params[0][rl]
             outcome = infos[rl]['outcomes'][0]
+            if outcome == 'no_minimum':
+                print('Minima of GCV function could not be found')
+                print('Returning NANs for regularization parameters.')
             if outcome == 'too_smooth':
                 print('Too smooth to find regularization parameter. Returning alpha=0.')
             elif outcome == 'no_root':
@@ -184,6 +187,32 @@ class Interpolate(object):
         self.chi_sq = res['chi_sq']
         self.reg_params = res['reg_params']
 
+    # interpolate.py:263-297 / :299-351
+    def gcv(self, A, b, W, reg_matrices, reg):
+        b = np.asarray(b, dtype=np.float64).ravel()
+        W = np.asarray(W, dtype=np.float64).ravel()
+        self._finite_or_raise(A, b, W)
+        eng = FitEngine.from_host_basis(self.ctx, A, reg_matrices, self.regularization_list)
+        eng.load_records(W[None, :], b[None, :])
+        saved = eng.regularization_list
+        eng.regularization_list = [reg]
+        params, infos = eng.search_gcv([np.arange(len(b), dtype=np.int32)])
+        eng.regularization_list = saved
+        eng.close()
+        if infos[reg]['outcomes'][0] != 'minimum':
+            raise ValueError('Minima of GCV function could not be found')
+        return params[0][reg]
+
+    def gcvobjfunct(self, alpha, A0, b0, W0, reg_matrices, reg):
+        b0 = np.asarray(b0, dtype=np.float64).ravel()
+        W0 = np.asarray(W0, dtype=np.float64).ravel()
+        self._finite_or_raise(A0, b0, W0)
+        eng = FitEngine.from_host_basis(self.ctx, A0, reg_matrices, self.regularization_list)
+        eng.load_records(W0[None, :], b0[None, :])
+        v = eng.gcv_objective(0, alpha, reg, np.arange(len(b0), dtype=np.int32))
+        eng.close()
+        return v
+
     def fit_records(self, lat, lon, alt, value, error, reg_matricies, calccov=True, record_slice=None):
         """The record loop of interpolate.py:511-579 as one device batch.
 
@@ -216,9 +245,11 @@ class Interpolate(object):
             W[~rec_ok] = 0.
         npts = [int(n) if ok else None for n, ok in zip(fin.sum(axis=1), rec_ok)]
 
+        method = self._check_method(self.reg_method)
+        point_lists = [np.nonzero(fin[t])[0].astype(np.int32) if npts[t] is not None else None for t in range(T)]
         eng = FitEngine(ctx, At, P, N, reg_matricies, self.regularization_list)
         try:
-            res = eng.fit(W, b, npts, calccov=calccov)
+            res = eng.fit(W, b, npts, calccov=calccov, method=method, point_lists=point_lists)
         finally:
             self.fit_stats = dict(eng.stats)
             eng.close()
