@@ -12,7 +12,6 @@ namespace {
 struct RcclApi {
     void* lib = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128-byte struct */ ...) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
