@@ -1,0 +1,87 @@
+"""Size-independent properties of the GPU path at BASELINE's full sizes (where the CPU oracle would take
+minutes to hours): linearity of the evaluation in the coefficients, agreement of the kernel variants and
+timestep tiles, invariance of a record's fit to the batch it is fitted in (records are independent)."""
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel
+
+pytestmark = pytest.mark.gpu
+
+CFG = ('[DEFAULT]\n[MODEL]\nNAME = sphharmlag\nMAXK = 4\nMAXL = 6\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\nLONCP = 262\n')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _eval(C, grid_n=128, hull=None):
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.estimate import Estimate
+    es = Estimate.from_arrays(C, None, synth.unix_times(len(C)), hull if hull is not None else np.zeros((4, 3)), CFG)
+    g = synth.query_grid(grid_n)
+    return es.evaluate_coeffs(C, *g, check_hull=hull is not None)
+
+
+def test_eval_128cubed_linearity_and_tiles():
+    """configs[1] grid (128^3 = 2 097 152 points): eval(a C1 + b C2) = a eval(C1) + b eval(C2); a row gives the
+    same values whether it is evaluated alone (tile of 1), in a tile of 4 or in a tile of 16."""
+    rng = np.random.default_rng(0)
+    C = rng.standard_normal((21, 144))
+    C[2] = 2.5 * C[0] - 0.75 * C[1]
+    out = _eval(C)                                     # tiles 16 + 4 + 1
+    assert out.shape == (21, 128**3) and np.all(np.isfinite(out))
+    assert rel(out[2], 2.5 * out[0] - 0.75 * out[1]) <= 1e-12
+    alone = _eval(C[20:21])                            # same row through the 1-tile kernel
+    assert rel(alone[0], out[20]) <= 1e-13
+    four = _eval(C[16:20])
+    assert rel(four[3], out[19]) <= 1e-13
+    sixteen = _eval(np.concatenate([C[5:21]]))         # rows 5..20 in a 16-tile
+    assert rel(sixteen[0], out[5]) <= 1e-13 and rel(sixteen[15], out[20]) <= 1e-13
+
+
+def test_fast_and_generic_eval_kernels_agree_at_128cubed():
+    code = ("import sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_properties import _eval\n"
+            "C = np.random.default_rng(1).standard_normal((2, 144))\n"
+            "np.save(sys.argv[1], _eval(C))\n") % (REPO, os.path.join(REPO, 'tests'))
+    outs = []
+    for mode in ('fast', 'generic'):
+        fn = '/tmp/vi_prop_%s.npy' % mode
+        env = dict(os.environ, VINTERP_EVAL=mode)
+        r = subprocess.run([sys.executable, '-c', code, fn], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.load(fn))
+        os.remove(fn)
+    assert rel(outs[0], outs[1]) <= 1e-12
+
+
+def test_hull_mask_is_independent_of_the_coefficients():
+    f = load_golden('fit_default')
+    rng = np.random.default_rng(2)
+    C = rng.standard_normal((5, 144))
+    out = _eval(C, grid_n=64, hull=f['hull_vert'])
+    mask = np.isnan(out)
+    assert 0.1 < mask[0].mean() < 0.9
+    assert np.all(mask == mask[0])
+
+
+def test_record_fit_is_independent_of_its_batch(tmp_path):
+    """Records carry no state into each other (interpolate.py:511): fitting a record alone or inside a batch of
+    others gives the same coefficients (screened, well-conditioned model; 1e-9 covers the different GEMM shapes)."""
+    from test_gpu_fit import make_interp, reg_of
+    f = load_golden('fit_k8l2')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    full = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    for t in (0, 3):
+        one = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'][t:t + 1], f['error'][t:t + 1], regm)
+        assert one['reg_params'][0][reg] == pytest.approx(full['reg_params'][t][reg], rel=1e-9)
+        assert rel(one['Coeffs'][0], full['Coeffs'][t]) <= 1e-9
+        assert rel(one['Covariance'][0], full['Covariance'][t]) <= 1e-8
+    # reversed batch order: same rows, reversed
+    rev = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'][::-1], f['error'][::-1], regm)
+    for t in range(4):
+        assert rel(rev['Coeffs'][3 - t], full['Coeffs'][t]) <= 1e-9

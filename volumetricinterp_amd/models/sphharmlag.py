@@ -27,6 +27,7 @@ import scipy.special as sp
 
 from .. import _lib
 from ..geodesy import geodetic2ecef
+from ._base import DeviceModel
 
 RE = 6371.2 * 1000.           # Earth radius (m), sphharmlag.py:9
 
@@ -34,7 +35,7 @@ SNAP_TOL = 1e-12              # degrees whose fractional parts differ by less sh
 HYP_TERMS = 256               # 2F1 series table length (converges for colatitudes < ~135 deg)
 
 
-class Model(object):
+class Model(DeviceModel):
     def __init__(self, config_file, ctx=None):
         self.read_config(config_file)
         self.nbasis = self.maxk * self.maxl**2
@@ -156,17 +157,9 @@ class Model(object):
         return dict(groups=out_groups, scale=scale, rot_cos=math.cos(theta0), rot_sin=math.sin(theta0),
                     kx=kx, ky=ky, nus=nus, nvs=nvs)
 
-    def handle(self, ctx=None):
-        """Create (once) the device-resident model and return its vi_model handle."""
-        if self._handle is not None:
-            return self._handle
-        if ctx is not None:
-            self._ctx = ctx
-        if self._ctx is None:
-            self._ctx = _lib.get_context()
+    def _create_handle(self, ctx):
         tb = self.device_tables()
         garr = (_lib.SphGroup * len(tb['groups']))()
-        keep = [tb, garr]
         for i, g in enumerate(tb['groups']):
             garr[i].v0 = g['v0']
             garr[i].nvmax = g['nvmax']
@@ -187,60 +180,13 @@ class Model(object):
         d.groups = garr
         d.coef_scale = tb['scale'].ctypes.data_as(_lib.c_double_p)
         h = _lib.VOIDP()
-        _lib.check(_lib.lib.vi_model_create(self._ctx.handle, C.byref(d), C.byref(h)), 'vi_model_create')
-        self._handle = h
-        self._keep = keep
-        return h
-
-    @property
-    def ctx(self):
-        self.handle()
-        return self._ctx
-
-    def __del__(self):
-        try:
-            if self._handle is not None and self._ctx is not None and self._ctx.handle:
-                _lib.lib.vi_model_destroy(self._handle)
-        except Exception:
-            pass
-        self._handle = None
-
-    # ------------------------------------------------------------------------------------------
-    def _upload_coords(self, gdlat, gdlon, gdalt):
-        ctx = self.ctx
-        return (ctx.to_device(np.asarray(gdlat, dtype=np.float64).ravel()),
-                ctx.to_device(np.asarray(gdlon, dtype=np.float64).ravel()),
-                ctx.to_device(np.asarray(gdalt, dtype=np.float64).ravel()))
+        _lib.check(_lib.lib.vi_model_create(ctx.handle, C.byref(d), C.byref(h)), 'vi_model_create')
+        return h, (tb, garr)
 
     # sphharmlag.py:324-359
     def transform_coord(self, gdlat, gdlon, gdalt):
-        h = self.handle()
-        gdlat = np.asarray(gdlat, dtype=np.float64)
-        P = gdlat.size
-        dlat, dlon, dalt = self._upload_coords(gdlat, gdlon, gdalt)
-        out = [self._ctx.empty(P) for _ in range(3)]
-        _lib.check(_lib.lib.vi_transform_f64(h, P, dlat.ptr, dlon.ptr, dalt.ptr, out[0].ptr, out[1].ptr, out[2].ptr),
-                   'vi_transform_f64')
-        return tuple(o.download().reshape(gdlat.shape) for o in out)
-
-    def basis_device(self, dlat, dlon, dalt, P, transposed=False):
-        """A on the device: (P, N) row-major, or the N x P layout the fit kernels consume."""
-        h = self.handle()
-        N = self.nbasis
-        dA = self._ctx.empty((N, P) if transposed else (P, N))
-        ld_p, ld_n = (1, P) if transposed else (N, 1)
-        _lib.check(_lib.lib.vi_basis_f64(h, P, dlat.ptr, dlon.ptr, dalt.ptr, dA.ptr, ld_p, ld_n), 'vi_basis_f64')
-        return dA
-
-    # sphharmlag.py:118-145
-    def basis(self, gdlat, gdlon, gdalt):
-        gdlat = np.asarray(gdlat, dtype=np.float64)
-        P = gdlat.size
-        if P == 0:
-            return np.zeros(gdlat.shape + (self.nbasis,))
-        dlat, dlon, dalt = self._upload_coords(gdlat, gdlon, gdalt)
-        A = self.basis_device(dlat, dlon, dalt, P).download()
-        return A.reshape(gdlat.shape + (self.nbasis,))
+        shape = np.asarray(gdlat).shape
+        return tuple(o.reshape(shape) for o in self._transform(gdlat, gdlon, gdalt))
 
     # ---- regularisation matrices (host; SURVEY A12) -------------------------------------------
     def eval_omega(self):
