@@ -118,6 +118,9 @@ int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const dou
 int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon,
                  const double* d_alt, int64_t T, const double* d_C,
                  const double* d_hull_eq, int32_t F, double hull_tol, double* d_out);
+/* device time (ms) of the evaluation kernel launches of the last vi_eval_f64 call on this context, from HIP
+ * events recorded on the context's stream around them (the preparation kernels are excluded) */
+int  vi_eval_kernel_ms(vi_ctx* ctx, double* ms);
 /* host-pointer convenience form of the same call */
 int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const double* h_lon,
                       const double* h_alt, int64_t T, const double* h_C,

@@ -45,6 +45,8 @@ extern "C" int vi_ctx_create(int device, vi_ctx** out)
     VI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     VI_HIP(hipEventCreate(&c->ev0));
     VI_HIP(hipEventCreate(&c->ev1));
+    VI_HIP(hipEventCreate(&c->evk0));
+    VI_HIP(hipEventCreate(&c->evk1));
     hipDeviceProp_t prop;
     VI_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -64,6 +66,8 @@ extern "C" void vi_ctx_destroy(vi_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evk0) (void)hipEventDestroy(c->evk0);
+    if (c->evk1) (void)hipEventDestroy(c->evk1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -162,6 +166,19 @@ extern "C" int vi_timer_stop_ms(vi_ctx* c, double* ms)
     VI_HIP(hipEventSynchronize(c->ev1));
     float f = 0.f;
     VI_HIP(hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = (double)f;
+    return VI_OK;
+}
+
+// duration of the evaluation kernel launches of the last vi_eval_f64 call (HIP events recorded on the
+// context's stream right around them, excluding the coefficient / hull preparation kernels)
+extern "C" int vi_eval_kernel_ms(vi_ctx* c, double* ms)
+{
+    VI_REQUIRE(c && ms, "null argument");
+    VI_REQUIRE(c->evk_valid, "no vi_eval_f64 call has been timed on this context");
+    VI_HIP(hipEventSynchronize(c->evk1));
+    float f = 0.f;
+    VI_HIP(hipEventElapsedTime(&f, c->evk0, c->evk1));
     *ms = (double)f;
     return VI_OK;
 }

@@ -664,6 +664,19 @@ int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double
     return VI_OK;
 }
 
+// records HIP events around the evaluation kernel launches of one vi_eval_f64 call (see vi_eval_kernel_ms)
+struct EvalTimer {
+    vi_ctx* c;
+    explicit EvalTimer(vi_ctx* ctx) : c(ctx)
+    {
+        c->evk_valid = hipEventRecord(c->evk0, c->stream) == hipSuccess;
+    }
+    ~EvalTimer()
+    {
+        if (c->evk_valid) c->evk_valid = hipEventRecord(c->evk1, c->stream) == hipSuccess;
+    }
+};
+
 bool use_fast_eval()
 {
     static int v = -1;
@@ -763,6 +776,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
                            m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
         VI_HIP(hipGetLastError());
         const int L = m->sph.maxl, K = m->sph.maxk;
+        EvalTimer timer(m->ctx);
         if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
 #define VI_FAST(LL, KK) \
     if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out)
@@ -784,6 +798,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         vi_set_error("vi_eval_f64: order MAXL=%d MAXK=%d beyond the compiled limits (24, 16)", L, K);
         return VI_ERR_UNSUPPORTED;
     }
+    EvalTimer timer(m->ctx);
     int64_t t = 0;
     while (t < T) {
         const int tc = (int)((T - t) >= 4 ? 4 : (T - t));

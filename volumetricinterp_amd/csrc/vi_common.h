@@ -43,6 +43,8 @@ struct vi_ctx {
     hipStream_t stream = nullptr;
     rocblas_handle blas = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;   // around the dominant kernel of the last vi_eval_f64 call
+    bool evk_valid = false;
     // grow-only device workspace for the fit entry points
     void* ws = nullptr;
     size_t ws_bytes = 0;
