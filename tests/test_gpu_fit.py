@@ -249,3 +249,25 @@ def test_gcv_on_gpu_matches_reference(tmp_path):
     assert abs(math.log10(it.gcv(A, f['value'][0], W, regm, reg)) - math.log10(f['alpha'][0])) <= 1e-4
     assert abs(math.log10(it.find_reg_param(A, f['value'][0], W, regm, method='gcv')[reg])
                - math.log10(f['alpha'][0])) <= 1e-4
+
+
+def test_full_batch_uses_walk_warm_start_and_keeps_parity(tmp_path):
+    """With >= 32 records the far tail of the bracket walk (alpha <= 1e-31) is solved in each record's
+    alpha -> 0 eigenbasis.  40 records = 10 copies of the screened golden records (record 1 brackets in
+    [-31, -30], i.e. on a walk value that now comes from the warm path): same parity gates as L7."""
+    f = load_golden('fit_k8l2')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    reps = 10
+    value = np.tile(f['value'], (reps, 1))
+    error = np.tile(f['error'], (reps, 1))
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], value, error, regm)
+    assert it.fit_stats.get('warm_solves', 0) > 40 * 60          # the walk tail really went through the warm path
+    T0 = f['value'].shape[0]
+    for i in range(reps * T0):
+        t = i % T0
+        assert rel(res['Coeffs'][i], f['Coeffs'][t]) <= 1e-6, i
+        assert rel(res['Covariance'][i], f['Covariance'][t]) <= 1e-5, i
+        assert abs(math.log10(res['reg_params'][i][reg]) - math.log10(f['alpha'][t])) <= 1e-7
+    # identical inputs -> identical outputs within the batch
+    assert rel(res['Coeffs'][4], res['Coeffs'][0]) <= 1e-12

@@ -163,16 +163,57 @@ class FitEngine(object):
             return False
         return self.N % 2 == 0 and 8 <= self.N <= 180
 
+    def walk_warm_enabled(self):
+        # the alpha -> 0 eigenbasis makes the walk systems alpha <= 1e-31 nearly diagonal (measured: 6.8 / 2.1 us
+        # per system for alpha in 1e-31..1e-60 / 1e-61..1e-101 against 22 us cold).  Setting it up costs one cold
+        # solve with eigenvectors per record, which only pays when the launch is full of records.
+        return (self.warm_enabled() and self.T >= 32 and os.environ.get('VINTERP_WALKWARM', '1') != '0')
+
+    WALK_WARM_BELOW = -31.0          # log10(alpha) at and below which walk requests use the alpha -> 0 basis
+    WALK_BASIS_ALPHA = 1e-60
+
     def _warm_reset(self):
-        self._warm_slot = {}
+        self._warm_slot = {}          # record -> slot of its Brent basis
+        self._walk_slot = {}          # record -> slot of its alpha -> 0 (walk) basis
+
+    def _warm_buffers(self, tag):
+        T, N = self.T, self.N
+        return (self._buf(tag + 'V', (T, N, N)), self._buf(tag + 'D1', (T, N, N)), self._buf(tag + 'D2', (T, N, N)),
+                self._buf(tag + 'yt', (T, N)))
+
+    def _warm_prepare(self, tag, slots, recs, alphas, name, dC_out, drank_out):
+        """Decompose X(alpha) of the given records with eigenvectors into the buffer set `tag`."""
+        N, h = self.N, self.ctx.handle
+        n = len(recs)
+        slot0 = len(slots)
+        for k, r in enumerate(recs):
+            slots[int(r)] = slot0 + k
+        dV, dD1, dD2, dyt = self._warm_buffers(tag)
+        dr = self._buf(tag + 'prec', (n,), np.int32).upload(np.asarray(recs, dtype=np.int32))
+        da = self._buf(tag + 'palpha', (n,)).upload(np.asarray(alphas, dtype=np.float64))
+        _lib.check(_lib.lib.vi_warm_prepare_f64(h, n, N, self.dAWA.ptr, dr.ptr, da.ptr, self.R[name].ptr, self.dy.ptr,
+                                                EPS, dC_out, drank_out, dV.offset_ptr(slot0 * N * N),
+                                                dD1.offset_ptr(slot0 * N * N), dD2.offset_ptr(slot0 * N * N),
+                                                dyt.offset_ptr(slot0 * N)), 'vi_warm_prepare_f64')
+
+    def _warm_solve(self, tag, slots, recs, dalpha_ptr, n, dC_out, drank_out):
+        N, h = self.N, self.ctx.handle
+        dV, dD1, dD2, dyt = self._warm_buffers(tag)
+        sl = np.array([slots[int(r)] for r in recs], dtype=np.int32)
+        dslot = self._buf(tag + 'slot', (n,), np.int32).upload(sl)
+        _lib.check(_lib.lib.vi_warm_solve_f64(h, n, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, dslot.ptr, dalpha_ptr, EPS,
+                                              dC_out, drank_out), 'vi_warm_solve_f64')
 
     def chi2_batch_search(self, rec, log10a, name):
-        """chi^2 for the search of `name` (all other parameters zero), B requests.  Integer log10(alpha) (the
-        bracket walk) are solved cold; the first non-integer request of a record (Brent's first iterate) is solved
-        cold *with eigenvectors*, which sets up the record's rotated system; later iterates use it."""
+        """chi^2 for the search of `name` (all other parameters zero), B requests.
+
+        * integer log10(alpha) - the bracket walk - are solved cold, except (full launches only) the far tail
+          alpha <= 1e-31, which is solved in the record's alpha -> 0 eigenbasis;
+        * the first non-integer request of a record (Brent's first iterate) is solved cold *with eigenvectors*,
+          which sets up the record's rotated system; later iterates use it."""
         rec = np.ascontiguousarray(rec, dtype=np.int32)
         log10a = np.asarray(log10a, dtype=np.float64)
-        B, N, T = len(rec), self.N, self.T
+        B, N = len(rec), self.N
         trace = os.environ.get('VINTERP_TRACE') == '1'
         if trace:
             import time
@@ -182,11 +223,12 @@ class FitEngine(object):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
+        walkwarm = is_int & (log10a <= self.WALK_WARM_BELOW) if self.walk_warm_enabled() else np.zeros(B, dtype=bool)
         warm = np.array([(not i) and (r in self._warm_slot) for r, i in zip(rec.tolist(), is_int.tolist())], dtype=bool)
         prep = (~is_int) & (~warm)
-        cold = is_int
-        order = np.concatenate([np.nonzero(cold)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
-        nc, npre, nw = int(cold.sum()), int(prep.sum()), int(warm.sum())
+        cold = is_int & (~walkwarm)
+        order = np.concatenate([np.nonzero(cold)[0], np.nonzero(walkwarm)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
+        nc, nww, npre, nw = int(cold.sum()), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
@@ -202,26 +244,25 @@ class FitEngine(object):
                 _lib.check(_lib.lib.vi_solve_trunc_f64(h, bc, N, dX.ptr, self.dy.ptr, drec.offset_ptr(s0), EPS,
                                                        dCall.offset_ptr(s0 * N), drank.offset_ptr(s0), N * EPS, None),
                            'vi_solve_trunc_f64')
-        if npre or nw:
-            dV = self._buf('w_V', (T, N, N))
-            dD1 = self._buf('w_D1', (T, N, N))
-            dD2 = self._buf('w_D2', (T, N, N))
-            dyt = self._buf('w_yt', (T, N))
+        o = nc
+        if nww:
+            recs = rec_o[o:o + nww]
+            need = sorted(set(int(r) for r in recs.tolist() if int(r) not in self._walk_slot))
+            if need:
+                scratchC = self._buf('ww_scratchC', (len(need), N))
+                scratchR = self._buf('ww_scratchR', (len(need),), np.int32)
+                self._warm_prepare('ww_', self._walk_slot, need, [self.WALK_BASIS_ALPHA] * len(need), name,
+                                   scratchC.ptr, scratchR.ptr)
+            self._warm_solve('ww_', self._walk_slot, recs, dal.offset_ptr(o), nww, dCall.offset_ptr(o * N),
+                             drank.offset_ptr(o))
+            o += nww
         if npre:
-            slot0 = len(self._warm_slot)
-            for k, r in enumerate(rec_o[nc:nc + npre].tolist()):
-                self._warm_slot[r] = slot0 + k
-            _lib.check(_lib.lib.vi_warm_prepare_f64(h, npre, N, self.dAWA.ptr, drec.offset_ptr(nc), dal.offset_ptr(nc),
-                                                    self.R[name].ptr, self.dy.ptr, EPS, dCall.offset_ptr(nc * N),
-                                                    drank.offset_ptr(nc), dV.offset_ptr(slot0 * N * N),
-                                                    dD1.offset_ptr(slot0 * N * N), dD2.offset_ptr(slot0 * N * N),
-                                                    dyt.offset_ptr(slot0 * N)), 'vi_warm_prepare_f64')
+            self._warm_prepare('w_', self._warm_slot, rec_o[o:o + npre].tolist(), alpha_o[o:o + npre], name,
+                               dCall.offset_ptr(o * N), drank.offset_ptr(o))
+            o += npre
         if nw:
-            slots = np.array([self._warm_slot[r] for r in rec_o[nc + npre:].tolist()], dtype=np.int32)
-            dslot = self._buf('w_slot', (nw,), np.int32).upload(slots)
-            _lib.check(_lib.lib.vi_warm_solve_f64(h, nw, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, dslot.ptr,
-                                                  dal.offset_ptr(nc + npre), EPS, dCall.offset_ptr((nc + npre) * N),
-                                                  drank.offset_ptr(nc + npre)), 'vi_warm_solve_f64')
+            self._warm_solve('w_', self._warm_slot, rec_o[o:o + nw], dal.offset_ptr(o), nw, dCall.offset_ptr(o * N),
+                             drank.offset_ptr(o))
         dchi = self._buf('w_chi2', (B,))
         _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dCall.ptr, drec.ptr, self.dW.ptr, self.db.ptr,
                                         dchi.ptr), 'vi_chi2_f64')
@@ -230,11 +271,11 @@ class FitEngine(object):
         out = np.empty(B)
         out[order] = tmp
         if trace:
-            print('[search round] B=%d cold=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
-                  (B, nc, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            print('[search round] B=%d cold=%d walk-warm=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, nww, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
-        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw
+        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nww
         return out
 
     def default_prefetch(self):
