@@ -54,8 +54,9 @@ typedef struct vi_sph_group {
     double v0;               /* fractional part of the degrees of this group (0 -> closed-form seeds) */
     int32_t nvmax;           /* largest integer part in the group */
     int32_t nterms;          /* length of the 2F1 series tables (0 when v0 == 0) */
-    const int32_t* pick;     /* [nvmax+1]   l whose degree has integer part j, or -1 */
-    const double* c;         /* [(nvmax+1) x maxl]  normalised recurrence coefficient c[j][m] */
+    const int32_t* pick;     /* [nvmax+2]   l whose degree has integer part j, or -1 */
+    const double* c;         /* [(nvmax+2) x maxl]  normalised recurrence coefficient c[j][m] (one degree beyond
+                                nvmax: grad_basis evaluates lpmv(m, nu+1, x), sphharmlag.py:177) */
     const double* seed_pref; /* [2 x maxl]  prefactor of the two seeds of chain m (v0 != 0) */
     const double* seed_q;    /* [2 x maxl x nterms]  term ratios of the 2F1 series (v0 != 0) */
 } vi_sph_group;
@@ -74,6 +75,8 @@ typedef struct vi_model_desc {
     const vi_sph_group* groups;
     const double* coef_scale;/* [maxl^2] per (l, signed m): Kvm(nu_l,|m|) (sphharmlag.py:305-321) x the
                                 lpmv negative-order factor x the chain normalisation */
+    const double* coef_scale1;/* [maxl^2] the same constant for degree nu_l + 1 (gradient basis only) */
+    const double* nu;        /* [maxl] the degrees nu_l (gradient basis only) */
     /* --- radbasfun --- */
     const double* centers;   /* [N x 3] ECEF metres (radbasfun.py:59) */
     double eps;              /* radbasfun.py:72 */
@@ -106,6 +109,10 @@ void vi_model_destroy(vi_model* model);
  * (P, N) layout; (1, P) gives the N x P layout the fit kernels consume (coalesced stores). */
 int  vi_basis_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
                   const double* d_alt, double* d_A, int64_t ld_p, int64_t ld_n);
+/* gradient basis: replaces Model.grad_basis (sphharmlag.py:148-184; next row N1 - the reference never calls it).
+ * G[p*ld_p + c*ld_c + n*ld_n], c = 0,1,2 = components along z, theta, phi.  sphharmlag only. */
+int  vi_grad_basis_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
+                       const double* d_alt, double* d_G, int64_t ld_p, int64_t ld_c, int64_t ld_n);
 /* model coordinates (z, theta, phi) of sphharmlag.py:324-359 `transform_coord`; ECEF x,y,z for RBF */
 int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
                       const double* d_alt, double* d_c0, double* d_c1, double* d_c2);

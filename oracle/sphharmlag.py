@@ -104,3 +104,33 @@ class SphHarmLagOracle:
                 cols.append(np.exp(-0.5 * z) * sp.eval_laguerre(k, z) * self.Az(v, m, phi) * sp.lpmv(m, v, ct))
         A = np.array(cols)                                     # (N, P)
         return np.moveaxis(A.reshape((-1,) + gdlat.shape), 0, -1)
+
+    # sphharmlag.py:284-302
+    def dAz(self, v, m, phi):
+        am = abs(m)
+        if m < 0:
+            return am * self.Kvm(v, am) * np.cos(am * phi)
+        return -1 * m * self.Kvm(v, am) * np.sin(am * phi)
+
+    # sphharmlag.py:148-184 (never called by the reference's own workflow; next row N1).
+    # 1-D inputs; returns (P, 3, N): components along z, theta, phi of the gradient of every basis function.
+    def grad_basis(self, gdlat, gdlon, gdalt):
+        z, theta, phi = self.transform_coord(gdlat, gdlon, gdalt)
+        rows = []
+        x = np.cos(theta)
+        y = np.sin(theta)
+        e = np.exp(-0.5 * z)
+        with np.errstate(all='ignore'):
+            for n in range(self.nbasis):
+                k, l, m = self.basis_numbers(n)
+                v = self.nu(n)
+                L0 = sp.eval_laguerre(k, z)
+                L1 = sp.eval_genlaguerre(k - 1, 1, z)
+                Pmv = sp.lpmv(m, v, x)
+                Pmv1 = sp.lpmv(m, v + 1, x)
+                A = self.Az(v, m, phi)
+                zhat = -0.5 * e * (L0 + 2 * L1) * Pmv * A * 100. / RE
+                that = e * L0 * (-(v + 1) * x * Pmv + (v - m + 1) * Pmv1) * A / (y * (z / 100. + 1) * RE)
+                phat = e * L0 * Pmv * self.dAz(v, m, phi) / (y * (z / 100. + 1) * RE)
+                rows.append([zhat, that, phat])
+        return np.array(rows).T

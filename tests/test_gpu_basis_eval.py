@@ -182,3 +182,17 @@ def test_rbf_estimate_vs_oracle():
         # |C| ~ 1e20 with heavy cancellation: compare against the size of the terms, not of the sum
         scale = np.linalg.norm(np.abs(A) @ np.abs(f['Coeffs'][t]))
         assert np.linalg.norm(out[t] - A @ f['Coeffs'][t]) <= 1e-11 * scale
+
+
+@pytest.mark.parametrize('tag', ['default', 'k3l4cap15', 'k2l5cap12p7'])
+def test_grad_basis_vs_reference(tag):
+    """Model.grad_basis (sphharmlag.py:148-184, next row N1): (P, 3, N) against the reference's own output."""
+    g = load_golden('grad_sph')
+    m = sph_model(g[tag + '_cfg'])
+    G = m.grad_basis(g[tag + '_lat'], g[tag + '_lon'], g[tag + '_alt'])
+    Gref = g[tag + '_G']
+    assert G.shape == Gref.shape
+    for c in range(3):
+        err = colnorm_err(G[:, c, :], Gref[:, c, :])
+        assert np.max(err) <= 1e-11, (tag, c, float(np.max(err)), int(np.argmax(err)))
+    assert m.grad_basis(np.zeros(0), np.zeros(0), np.zeros(0)).shape == (0, 3, m.nbasis)

@@ -184,3 +184,14 @@ def test_gcv_matches_reference():
     for t in range(2):
         assert abs(np.log10(params[t]['curvature']) - np.log10(f['alpha'][t])) <= 1e-6
         assert rel(C[t], f['Coeffs'][t]) <= 1e-5
+
+
+@pytest.mark.parametrize('tag', ['default', 'k3l4cap15', 'k2l5cap12p7'])
+def test_grad_basis_matches_reference(tag):
+    g = load_golden('grad_sph')
+    m = make_sph(g[tag + '_cfg'])
+    G = m.grad_basis(g[tag + '_lat'], g[tag + '_lon'], g[tag + '_alt'])
+    Gref = g[tag + '_G']
+    assert G.shape == Gref.shape == (len(g[tag + '_lat']), 3, m.nbasis)
+    for c in range(3):
+        assert np.max(colnorm_err(G[:, c, :], Gref[:, c, :])) <= 1e-13

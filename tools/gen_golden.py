@@ -314,6 +314,24 @@ def gen_fit(workdir):
          self_noise=np.array([rel(it2.Coeffs[t], it.Coeffs[t]) for t in range(2)]))
 
 
+def gen_grad(workdir):
+    """grad_basis (sphharmlag.py:148-184): advertised by the reference, never called by its own workflow."""
+    out = {}
+    for tag, kw in {'default': dict(maxk=4, maxl=6, cap=10), 'k3l4cap15': dict(maxk=3, maxl=4, cap=15),
+                    'k2l5cap12p7': dict(maxk=2, maxl=5, cap=12.7)}.items():
+        m = ref_model(config_text(**kw))
+        lat, lon, alt = sample_points(40, seed=21)
+        lat, lon, alt = lat[2:], lon[2:], alt[2:]            # drop the two points at the poles of the rotation (1/sin theta)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            G = m.grad_basis(lat, lon, alt)
+        out[tag + '_cfg'] = np.array([kw['maxk'], kw['maxl'], kw['cap']], dtype=np.float64)
+        out[tag + '_lat'], out[tag + '_lon'], out[tag + '_alt'] = lat, lon, alt
+        out[tag + '_G'] = G
+        print(tag, G.shape, 'finite', bool(np.isfinite(G).all()))
+    save('grad_sph', **out)
+
+
 def gen_gcv(workdir):
     """Generalised cross validation (interpolate.py:263-351) on the well-conditioned MAXK=8, MAXL=2 model."""
     regs = np.load(os.path.join(GOLD, 'regmat.npz'))
@@ -398,7 +416,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     setup_reference(args.ref)
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
-    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('eval', gen_eval)]
+    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue

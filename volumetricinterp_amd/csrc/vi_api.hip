@@ -245,7 +245,7 @@ extern "C" int vi_model_create(vi_ctx* c, const vi_model_desc* d, vi_model** out
                 rc = VI_ERR_INVALID;
                 break;
             }
-            for (int j = 0; j <= G.nvmax; ++j)
+            for (int j = 0; j <= G.nvmax + 1; ++j)
                 if (G.pick[j] >= d->maxl || (G.pick[j] >= 0 && G.pick[j] > j)) {
                     vi_set_error("vi_model_create: group %d pick[%d]=%d invalid", g, j, G.pick[j]);
                     rc = VI_ERR_INVALID;
@@ -255,7 +255,7 @@ extern "C" int vi_model_create(vi_ctx* c, const vi_model_desc* d, vi_model** out
             hg[g].nvmax = G.nvmax;
             if (g == 0) m->nvmax0 = G.nvmax;
             hg[g].nterms = G.nterms;
-            const size_t nj = (size_t)G.nvmax + 1;
+            const size_t nj = (size_t)G.nvmax + 2;
             if ((rc = upload(m, G.pick, nj, &hg[g].pick)) != VI_OK) break;
             if ((rc = upload(m, G.c, nj * d->maxl, &hg[g].c)) != VI_OK) break;
             if ((rc = upload(m, G.seed_pref, G.nterms ? (size_t)2 * d->maxl : 0, &hg[g].pref)) != VI_OK) break;
@@ -263,6 +263,8 @@ extern "C" int vi_model_create(vi_ctx* c, const vi_model_desc* d, vi_model** out
         }
         if (rc == VI_OK) rc = upload(m, hg.data(), hg.size(), &S.groups);
         if (rc == VI_OK) rc = upload(m, d->coef_scale, (size_t)d->maxl * d->maxl, &S.scale);
+        if (rc == VI_OK && d->coef_scale1) rc = upload(m, d->coef_scale1, (size_t)d->maxl * d->maxl, &S.scale1);
+        if (rc == VI_OK && d->nu) rc = upload(m, d->nu, (size_t)d->maxl, &S.nu);
     } else if (d->kind == VI_MODEL_RADBASFUN) {
         if (d->nbasis < 1 || !d->centers || !(d->eps != 0.0)) {
             vi_set_error("vi_model_create: inconsistent radbasfun description");

@@ -201,6 +201,110 @@ __global__ __launch_bounds__(BLOCK) void k_basis_sph(SphDev M, int64_t P, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Gradient basis (sphharmlag.py:148-184): for every basis function the components along z, theta, phi,
+//   zhat = -e/2 (L0 + 2 L1) Pmv A 100/RE,  that = e L0 (-(v+1) x Pmv + (v-m+1) Pmv1) A / (y (z/100+1) RE),
+//   phat = e L0 Pmv dAz / (y (z/100+1) RE),
+// with L1 = eval_genlaguerre(k-1, 1, z), Pmv1 = lpmv(m, v+1, x).  Same chains as the basis, run one degree
+// further: when the chain has reached degree nu_l + 1, prev holds P at nu_l and cur at nu_l + 1.
+template <int LCAP, int KCAP>
+__global__ __launch_bounds__(BLOCK) void k_grad_sph(SphDev M, int64_t P, const double* __restrict__ lat,
+                                                    const double* __restrict__ lon, const double* __restrict__ alt,
+                                                    double* __restrict__ Gout, int64_t ld_p, int64_t ld_c, int64_t ld_n)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t pc = p < P ? p : P - 1;
+    const bool active = p < P;
+    const Geom g = sph_geom(M, lat[pc], lon[pc], alt[pc]);
+    double* Gp = Gout + pc * ld_p;
+    const int maxl = M.maxl, maxk = M.maxk, L2 = maxl * maxl;
+    double L0[KCAP], L1[KCAP];          // L_k(z) and L^(1)_{k-1}(z)
+    laguerre<KCAP>(maxk, g.z, L0);
+    L1[0] = 0.0;                        // eval_genlaguerre(-1, 1, z) = 0
+    if (KCAP > 1) L1[1] = 1.0;
+    if (KCAP > 2) L1[2] = 2.0 - g.z;
+#pragma unroll
+    for (int k = 3; k < KCAP; ++k) {    // n L^(1)_n = (2n - z) L^(1)_{n-1} - n L^(1)_{n-2},  n = k-1
+        const int n = k - 1;
+        L1[k] = ((2.0 * n - g.z) * L1[k - 1] - (double)n * L1[k - 2]) / (double)n;
+    }
+    const double e = exp(-0.5 * g.z);
+    const double x = g.x, y = g.s;
+    const double inv_hr = 1.0 / (y * (g.z / 100.0 + 1.0) * M.RE);       // 1 / (y (z/100+1) RE)
+    const double zfac = -0.5 * e * 100.0 / M.RE;
+    double cm[LCAP], sm[LCAP];
+    cm[0] = 1.0;
+    sm[0] = 0.0;
+#pragma unroll
+    for (int m = 1; m < LCAP; ++m) {
+        cm[m] = cm[m - 1] * g.cphi - sm[m - 1] * g.sphi;
+        sm[m] = sm[m - 1] * g.cphi + cm[m - 1] * g.sphi;
+    }
+    const double zz = 0.5 * (1.0 - x);
+    for (int gi = 0; gi < M.ngroups; ++gi) {
+        const SphGroupDev G = M.groups[gi];
+        const bool intseed = (G.nterms == 0);
+        double cur[LCAP], prev[LCAP];
+#pragma unroll
+        for (int m = 0; m < LCAP; ++m) { cur[m] = 0.0; prev[m] = 0.0; }
+        double pmm = 1.0, spow = 1.0;
+        for (int j = 0; j <= G.nvmax + 1; ++j) {
+            const double* __restrict__ cj = G.c + (size_t)j * maxl;
+#pragma unroll
+            for (int m = 0; m < LCAP; ++m) {
+                if (m < maxl) {
+                    if (j > m + 1) {
+                        const double nw = fma(x, cur[m], -(cj[m] * prev[m]));
+                        prev[m] = cur[m];
+                        cur[m] = nw;
+                    } else if (j == m) {
+                        if (m > 0) { pmm *= -(2.0 * m - 1.0) * g.s; spow *= g.s; }
+                        if (intseed) cur[m] = pmm;
+                        else cur[m] = G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz);
+                    } else if (j == m + 1) {
+                        prev[m] = cur[m];
+                        if (intseed) cur[m] = x * (2.0 * m + 1.0) * cur[m];
+                        else cur[m] = G.pref[maxl + m] * spow *
+                                      hyp_series(G.q + (size_t)(maxl + m) * G.nterms, G.nterms, zz);
+                    }
+                }
+            }
+            const int l = j >= 1 ? G.pick[j - 1] : -1;      // degree nu_l + 1 reached
+            if (l >= 0) {
+                const int r0 = l * (l + 1);
+                const double v = M.nu[l];
+#pragma unroll
+                for (int m = 0; m < LCAP; ++m) {
+                    if (m <= l) {
+#pragma unroll
+                        for (int sgn = 0; sgn < 2; ++sgn) {
+                            if (sgn == 1 && m == 0) continue;
+                            const int r = sgn ? r0 - m : r0 + m;
+                            const double ms = sgn ? -(double)m : (double)m;            // signed order
+                            const double Q0 = M.scale[r] * prev[m];                      // Kvm * lpmv(m, v, x)
+                            const double Q1 = M.scale1[r] * cur[m];                      // Kvm * lpmv(m, v+1, x)
+                            const double trig = sgn ? sm[m] : cm[m];
+                            const double dtrig = sgn ? (double)m * cm[m] : -(double)m * sm[m];
+                            const double tz = zfac * Q0 * trig;
+                            const double tt = e * (-(v + 1.0) * x * Q0 + (v - ms + 1.0) * Q1) * trig * inv_hr;
+                            const double tp = e * Q0 * dtrig * inv_hr;
+#pragma unroll
+                            for (int k = 0; k < KCAP; ++k) {
+                                if (k < maxk && active) {
+                                    double* o = Gp + (int64_t)(k * L2 + r) * ld_n;
+                                    o[0] = tz * (L0[k] + 2.0 * L1[k]);
+                                    o[ld_c] = tt * L0[k];
+                                    o[2 * ld_c] = tp * L0[k];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: fused evaluation for TT timesteps per pass.  Cp is the coefficient tile reordered to
 // [t][r = l(l+1)+m][k] and pre-multiplied by the per-(l,m) constant (see k_prep_coef).
 template <int KCAP, int TT>
@@ -707,6 +811,31 @@ extern "C" int vi_basis_f64(vi_model* m, int64_t P, const double* d_lat, const d
     }
     hipLaunchKernelGGL(k_basis_rbf, dim3(nblocks(P, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, P, d_lat, d_lon,
                        d_alt, d_A, ld_p, ld_n);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+extern "C" int vi_grad_basis_f64(vi_model* m, int64_t P, const double* d_lat, const double* d_lon, const double* d_alt,
+                                 double* d_G, int64_t ld_p, int64_t ld_c, int64_t ld_n)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_G, "null argument");
+    VI_REQUIRE(P >= 0, "negative point count");
+    if (m->kind != VI_MODEL_SPHHARMLAG || !m->sph.scale1 || !m->sph.nu) {
+        vi_set_error("vi_grad_basis_f64: only the sphharmlag model provides a gradient basis");
+        return VI_ERR_UNSUPPORTED;
+    }
+    if (P == 0) return VI_OK;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    const int L = m->sph.maxl, K = m->sph.maxk;
+    const dim3 grid(nblocks(P, BLOCK)), block(BLOCK);
+    if (L <= 6 && K <= 4)
+        hipLaunchKernelGGL((k_grad_sph<6, 4>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, d_G, ld_p, ld_c, ld_n);
+    else if (L <= 12 && K <= 8)
+        hipLaunchKernelGGL((k_grad_sph<12, 8>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, d_G, ld_p, ld_c, ld_n);
+    else {
+        vi_set_error("vi_grad_basis_f64: order MAXL=%d MAXK=%d beyond the compiled limits (12, 8)", L, K);
+        return VI_ERR_UNSUPPORTED;
+    }
     VI_HIP(hipGetLastError());
     return VI_OK;
 }

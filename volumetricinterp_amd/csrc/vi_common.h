@@ -70,6 +70,8 @@ struct SphDev {
     double rc, rs, kx, ky, RE;
     const SphGroupDev* groups;
     const double* scale;    // [maxl^2]
+    const double* scale1;   // [maxl^2] for degree nu_l + 1 (gradient basis)
+    const double* nu;       // [maxl]
 };
 
 struct RbfDev {

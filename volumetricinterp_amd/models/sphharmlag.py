@@ -109,17 +109,19 @@ class Model(DeviceModel):
             else:
                 groups.append(dict(v0=float(v0s[l]), members=[l]))
         scale = np.zeros(maxl * maxl)
+        scale1 = np.zeros(maxl * maxl)        # same for degree nu_l + 1 (grad_basis needs lpmv(m, nu+1, x))
         out_groups = []
         for g in groups:
             v0 = np.longdouble(g['v0'])
             nvmax = int(max(nvs[l] for l in g['members']))
-            pick = np.full(nvmax + 1, -1, dtype=np.int32)
+            pick = np.full(nvmax + 2, -1, dtype=np.int32)
             for l in g['members']:
                 pick[nvs[l]] = l
-            c = np.zeros((nvmax + 1, maxl))
-            s = np.ones((nvmax + 1, maxl), dtype=np.longdouble)      # chain normalisation s[j][m]
+            # one row more than the largest degree: grad_basis also needs the degrees nu_l + 1
+            c = np.zeros((nvmax + 2, maxl))
+            s = np.ones((nvmax + 2, maxl), dtype=np.longdouble)      # chain normalisation s[j][m]
             for m in range(maxl):
-                for j in range(m + 2, nvmax + 1):
+                for j in range(m + 2, nvmax + 2):
                     a = (2 * (v0 + j) - 1) / (v0 + j - m)
                     b = (v0 + j - 1 + m) / (v0 + j - m)
                     s[j, m] = s[j - 1, m] * a
@@ -129,12 +131,16 @@ class Model(DeviceModel):
                 for m in range(0, l + 1):
                     K = self.Kvm(v, m)
                     sjm = float(s[nvs[l], m])
+                    sjm1 = float(s[nvs[l] + 1, m])
                     scale[l * (l + 1) + m] = K * sjm
+                    scale1[l * (l + 1) + m] = K * sjm1
                     if m > 0:
                         # scipy.special.lpmv for negative order: (-1)^m Gamma(v-m+1)/Gamma(v+m+1) P_v^m
                         with np.errstate(all='ignore'):
                             neg = (-1.)**m * sp.gamma(v - m + 1) / sp.gamma(v + m + 1)
+                            neg1 = (-1.)**m * sp.gamma(v + 1 - m + 1) / sp.gamma(v + 1 + m + 1)
                             scale[l * (l + 1) - m] = K * neg * sjm
+                            scale1[l * (l + 1) - m] = K * neg1 * sjm1
             entry = dict(v0=float(g['v0']), nvmax=nvmax, pick=pick, c=np.ascontiguousarray(c), nterms=0,
                          pref=None, q=None, members=list(g['members']))
             if g['v0'] != 0.0:
@@ -154,7 +160,7 @@ class Model(DeviceModel):
                 entry.update(nterms=nt, pref=np.ascontiguousarray(pref), q=np.ascontiguousarray(q))
             out_groups.append(entry)
         theta0, kx, ky = self._rotation()
-        return dict(groups=out_groups, scale=scale, rot_cos=math.cos(theta0), rot_sin=math.sin(theta0),
+        return dict(groups=out_groups, scale=scale, scale1=scale1, rot_cos=math.cos(theta0), rot_sin=math.sin(theta0),
                     kx=kx, ky=ky, nus=nus, nvs=nvs)
 
     def _create_handle(self, ctx):
@@ -179,6 +185,9 @@ class Model(DeviceModel):
         d.ngroups = len(tb['groups'])
         d.groups = garr
         d.coef_scale = tb['scale'].ctypes.data_as(_lib.c_double_p)
+        d.coef_scale1 = tb['scale1'].ctypes.data_as(_lib.c_double_p)
+        tb['nus'] = np.ascontiguousarray(tb['nus'], dtype=np.float64)
+        d.nu = tb['nus'].ctypes.data_as(_lib.c_double_p)
         h = _lib.VOIDP()
         _lib.check(_lib.lib.vi_model_create(ctx.handle, C.byref(d), C.byref(h)), 'vi_model_create')
         return h, (tb, garr)
@@ -187,6 +196,27 @@ class Model(DeviceModel):
     def transform_coord(self, gdlat, gdlon, gdalt):
         shape = np.asarray(gdlat).shape
         return tuple(o.reshape(shape) for o in self._transform(gdlat, gdlon, gdalt))
+
+    # sphharmlag.py:284-302
+    def dAz(self, v, m, phi):
+        if m < 0:
+            return abs(m) * self.Kvm(v, abs(m)) * np.cos(abs(m) * phi)
+        return -1 * m * self.Kvm(v, abs(m)) * np.sin(abs(m) * phi)
+
+    # sphharmlag.py:148-184 (advertised by the reference, never called by its own workflow - SURVEY F9, row N1)
+    def grad_basis(self, gdlat, gdlon, gdalt):
+        """Gradient of every basis function: (P, 3, N), components along z, theta, phi; 1-D inputs as in the
+        reference."""
+        gdlat = np.asarray(gdlat, dtype=np.float64)
+        P, N = gdlat.size, self.nbasis
+        if P == 0:
+            return np.zeros((0, 3, N))
+        h = self.handle()
+        dlat, dlon, dalt = self._upload_coords(gdlat, gdlon, gdalt)
+        dG = self._ctx.empty((P, 3, N))
+        _lib.check(_lib.lib.vi_grad_basis_f64(h, P, dlat.ptr, dlon.ptr, dalt.ptr, dG.ptr, 3 * N, N, 1),
+                   'vi_grad_basis_f64')
+        return dG.download()
 
     # ---- regularisation matrices (host; SURVEY A12) -------------------------------------------
     def eval_omega(self):
