@@ -159,20 +159,32 @@ class Comm(object):
         else:
             raise ValueError('unknown backend %r' % backend)
 
-    def _init_rccl(self):
+    def _init_rccl(self, timeout=90.):
+        """Create the RCCL communicator.  The call is guarded by a timeout: a bootstrap that cannot complete (no
+        usable network interface for the out-of-band exchange, for instance) must degrade to the control-socket
+        broadcast, not hang the run."""
         import ctypes as C
+        import threading
         from . import _lib
-        ok = True
         ident = b''
         if self.rank == 0:
             buf = C.create_string_buffer(128)
-            ok = _lib.lib.vi_rccl_unique_id(buf) == 0
-            ident = buf.raw if ok else b''
+            if _lib.lib.vi_rccl_unique_id(buf) == 0:
+                ident = buf.raw
         ident = self.grp.bcast(ident)
+        result = {}
+
+        def work():
+            result['rc'] = _lib.lib.vi_rccl_init(self.ctx.handle, self.world, self.rank, ident)
+
+        ok = False
         if len(ident) == 128:
-            ok = _lib.lib.vi_rccl_init(self.ctx.handle, self.world, self.rank, ident) == 0
-        else:
-            ok = False
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(timeout)
+            ok = (not th.is_alive()) and result.get('rc') == 0
+            if th.is_alive():
+                self.notes.append('ncclCommInitRank did not return within %.0f s' % timeout)
         oks = self.grp.allgather(b'1' if ok else b'0')
         self.rccl_ready = all(o == b'1' for o in oks)
         if not self.rccl_ready:
