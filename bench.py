@@ -80,6 +80,12 @@ def cpu_baseline(lat, lon, alt, value, error, R, grid_n):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries loaded below (RCCL prints a version banner on
+    # communicator creation) write to file descriptor 1 directly, so keep a private handle on the real stdout
+    # and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -184,7 +190,8 @@ def main():
             'timesteps_per_sec': args.steps * T * world / elapsed,
             'breakdown_ms': {'fit': float(np.mean(fit_ms)), 'eval_kernel': ev,
                              'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
-                             'fit_outcome': res['search']['curvature']['outcomes']},
+                             'fit_outcome': res['search']['curvature']['outcomes'],
+                             'root_finder': [i.get('finder') for i in res['search']['curvature']['info']]},
             'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
             'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
             'roofline': {'kernel': 'k_eval_sph_fast<6,4,1>', 'bound': 'hbm',
@@ -199,7 +206,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
         elif world == 1:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + '\n')
+        real_stdout.flush()
     comm.close()
 
 

@@ -28,7 +28,7 @@ FUNCS = [
     (lambda x: math.exp(-x) - 1e-3 * x**2 - 0.5, -1., 4.),
     (lambda x: (x - 0.3) * (1 + 50 * (x - 0.3)**2), -1., 1.),          # odd, steep
     (lambda x: math.tanh(40 * (x + 20.37)) * 500 + 3, -21., -20.),     # step-like, as chi2-nu can be
-    (lambda x: 1e-9 * (x + 30.5), -31., -30.),
+    (lambda x: 1e-9 * (x + 30.37), -31., -30.),
     (lambda x: x, -1., 0.),                                             # root at the bracket end
 ]
 
@@ -130,23 +130,60 @@ def test_run_batched_matches_sequential():
     assert len(counts) < 25
 
 
-@pytest.mark.parametrize('case', range(len(FUNCS) - 1))
-@pytest.mark.parametrize('K', [15, 255])
-def test_multisection_finds_brents_root(case, K):
-    f, a, b = FUNCS[case]
-    ref = scipy.optimize.brentq(f, a, b)
-    g = AS.multisection_gen(a, b, f(a), f(b), K)
+def drive_ms(g, f):
+    """Run a multisection coroutine; returns (result or None, number of rounds, K seen)."""
     rounds = 0
     try:
         xs = next(g)
         while True:
             rounds += 1
-            assert len(xs) == K
             xs = g.send([f(x) for x in xs])
     except StopIteration as stop:
-        root, nr, calls = stop.value
-    assert abs(root - ref) <= 4e-12 + 4e-15 * abs(ref)
-    assert nr == rounds and rounds <= math.ceil(math.log((b - a) / 2e-12) / math.log(K + 1)) + 1
+        return stop.value, rounds
+
+
+@pytest.mark.parametrize('case', range(len(FUNCS) - 1))
+@pytest.mark.parametrize('K', [15, 255])
+def test_multisection_finds_brents_root(case, K):
+    f, a, b = FUNCS[case]
+    ref = scipy.optimize.brentq(f, a, b)
+    res, rounds = drive_ms(AS.multisection_gen(a, b, f(a), f(b), K), f)
+    root, nr, calls = res
+    # stops at a 1e-7 bracket and finishes with the secant point: far inside the 1e-7 parity tolerance on log10 alpha
+    assert abs(root - ref) <= 1e-10
+    assert nr == rounds and calls == K * rounds
+    assert rounds <= math.ceil(math.log((b - a) / AS.MS_XTOL) / math.log(K + 1))
+
+
+def test_multisection_guard_hands_multi_root_brackets_back():
+    # three roots inside the bracket (measured shape of chi^2 - nu on the screened MAXK=8, MAXL=2 fixture): which one
+    # brentq returns depends on its iterates, so multisection must refuse and the search must equal plain Brent
+    f = lambda x: (x + 28.4698) * (x + 28.0745) * (x + 28.2)                  # noqa: E731
+    res, rounds = drive_ms(AS.multisection_gen(-29., -28., f(-29.), f(-28.), 255), f)
+    assert res is None and rounds == 1
+    # NaN or an exact zero among the samples also hands back
+    res, _ = drive_ms(AS.multisection_gen(-1., 1., -1., 1., 3), lambda x: x)       # sample at exactly 0
+    assert res is None
+    res, _ = drive_ms(AS.multisection_gen(-1., 1., -1., 1., 4), lambda x: float('nan') if x > 0.5 else x - 0.1)
+    assert res is None
+    # end points that are already roots / same sign: Brent's business
+    assert drive_ms(AS.multisection_gen(-1., 0., -1., 0., 15), lambda x: x)[0] is None
+    assert drive_ms(AS.multisection_gen(-1., 0., 1., 2., 15), lambda x: x)[0] is None
+
+
+def test_search_falls_back_to_brent_on_multi_root_bracket():
+    # chi^2 - nu with three crossings in [-29, -28]; nu = 0.6 * 550
+    chi2 = lambda a: 330. + 4e3 * (a + 28.4698) * (a + 28.0745) * (a + 28.2) if a < -27.5 else 330. + 50. * (a + 28.6)  # noqa: E731
+    (o1, a1, i1), _ = drive(AS.chi2_search_gen(550), chi2)
+    g = AS.chi2_search_gen(550, multisection=255)
+    try:
+        x = next(g)
+        while True:
+            x = g.send([chi2(v) for v in x] if isinstance(x, tuple) else chi2(x))
+    except StopIteration as stop:
+        o2, a2, i2 = stop.value
+    assert o1 == o2 == 'root' and a1 == a2                   # bit-identical: same Brent iterates
+    assert i1['finder'] == i2['finder'] == 'brentq'
 
 
 def test_search_with_multisection_on_smooth_chi2():
@@ -164,5 +201,6 @@ def test_search_with_multisection_on_smooth_chi2():
         except StopIteration as stop:
             o2, a2, info = stop.value
         assert o1 == o2 == 'root'
-        assert abs(math.log10(a1) - math.log10(a2)) <= 1e-11
-        assert nreq <= 7                            # 64^-7 < 2e-12: dependent rounds after the walk
+        assert abs(math.log10(a1) - math.log10(a2)) <= 1e-10
+        assert info['finder'] == 'multisection'
+        assert nreq <= 4                            # 64^-4 < 1e-7: dependent rounds after the walk

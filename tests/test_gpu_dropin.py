@@ -101,7 +101,9 @@ def test_config_to_hdf5_to_estimate(tmp_path):
     it2.calc_coeffs(starttime=dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(f['utime'][1, 0])),
                     endtime=dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(f['utime'][2, 1])))
     assert it2.Coeffs.shape == (2, 32)
-    assert rel(it2.Coeffs[1], it.Coeffs[2]) <= 1e-9
+    # same record in a batch of 2 instead of 3: the guarded multisection samples other abscissae (K = 256 // T - 1), so
+    # the root moves within its 1e-10 resolution in log10 alpha - far inside the 1e-6 budget
+    assert rel(it2.Coeffs[1], it.Coeffs[2]) <= 1e-7
 
 
 def test_unsupported_regularisation_name_raises_keyerror(tmp_path):

@@ -96,10 +96,14 @@ def test_truncated_solve_rank_deficient_indefinite():
         assert rel(H[i], Hx) <= 1e-7
 
 
+@pytest.mark.parametrize('root', ['auto', 'brent'])
 @pytest.mark.parametrize('name', ['fit_k8l2', 'fit_k8l2_c2'])
-def test_L7_fit_records_screened(tmp_path, name):
+def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
     """End to end on screened fixtures (reference self-noise < 1e-8): north-star tolerance 1e-6 on the
-    coefficients, same alpha, same chi^2, covariance within 1e-5."""
+    coefficients, same alpha, same chi^2, covariance within 1e-5.  'auto' = guarded multisection for few records
+    (falls back to Brent on the multi-root brackets these fixtures contain), 'brent' = the reference's iteration
+    only."""
+    monkeypatch.setenv('VINTERP_ROOT', root)
     f = load_golden(name)
     assert np.all(f['self_noise'] < 1e-8)
     regm, reg = reg_of(f)
@@ -110,8 +114,9 @@ def test_L7_fit_records_screened(tmp_path, name):
         assert rel(res['Covariance'][t], f['Covariance'][t]) <= 1e-5, t
         assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-6 * f['chi_sq'][t]
         assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-7
-    # work accounting: one solve per distinct alpha (memoised, plus walk prefetch) - far fewer than the reference
-    assert it.fit_stats['solves'] < int(f['evalC_calls'])
+    if root == 'brent':
+        # work accounting: one solve per distinct alpha (memoised, plus walk prefetch) - far fewer than the reference
+        assert it.fit_stats['solves'] < int(f['evalC_calls'])
 
 
 def test_fit_edge_outcomes(tmp_path):

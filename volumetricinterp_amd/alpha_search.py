@@ -86,22 +86,26 @@ def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
     raise RuntimeError('Failed to converge after %d iterations.' % maxiter)
 
 
-def multisection_gen(xa, xb, fa, fb, K, xtol=XTOL):
-    """Latency-optimised replacement for the sequential Brent iteration when the GPU is otherwise idle
-    (a single record): every round evaluates K equispaced interior points of the current bracket *in one
-    batch* and keeps the sub-interval with the sign change nearest to xb, shrinking the bracket by K+1 per
-    round until it is shorter than xtol; the root is then the secant point of the last bracket.  For a
-    continuous objective it returns the same root as brentq to within xtol (2e-12 in log10 alpha), in
-    ceil(log(1/xtol)/log(K+1)) rounds (5 for K = 255) instead of Brent's 10-30 dependent evaluations.
+MS_XTOL = 1e-7          # multisection stops at this bracket width (log10 alpha); the secant point finishes
 
-    Yields a tuple of K abscissae, receives the K function values.  Returns (root, rounds, funcalls)."""
+
+def multisection_gen(xa, xb, fa, fb, K, xtol=MS_XTOL):
+    """Latency-optimised replacement for the sequential Brent iteration when the GPU is otherwise idle (a
+    single record or a few): every round evaluates K equispaced interior points of the current bracket *in
+    one batch* and keeps the sub-interval with the sign change, shrinking the bracket by K+1 per round until it
+    is shorter than xtol; the root is then the secant point of the last bracket (error ~ xtol^2 f''/f').
+
+    GUARD.  chi^2(alpha) - nu is not monotone (the curvature matrix is indefinite) and a unit bracket can hold
+    several roots; which of them ``brentq`` returns is decided by its iterate sequence.  Multisection is
+    therefore only used while every round shows EXACTLY ONE sign change among its K+2 finite samples - then the
+    bracket holds one root at the sampling resolution and any bracketing method, Brent included, converges to
+    it.  On anything else (a second sign change, a NaN, an exact zero) the generator returns None and the
+    caller runs the reference's Brent iteration on the original bracket.
+
+    Yields a tuple of K abscissae, receives the K function values.  Returns (root, rounds, funcalls) or None."""
     lo, hi, flo, fhi = xa, xb, fa, fb
-    if flo == 0:
-        return lo, 0, 0
-    if fhi == 0:
-        return hi, 0, 0
-    if _signbit(flo) == _signbit(fhi):
-        raise ValueError('f(a) and f(b) must have different signs')
+    if flo == 0 or fhi == 0 or math.isnan(flo) or math.isnan(fhi) or _signbit(flo) == _signbit(fhi):
+        return None
     rounds = funcalls = 0
     while abs(hi - lo) > xtol:
         xs = tuple(lo + (hi - lo) * (k + 1) / (K + 1) for k in range(K))
@@ -109,22 +113,18 @@ def multisection_gen(xa, xb, fa, fb, K, xtol=XTOL):
         rounds += 1
         funcalls += K
         pts = [(lo, flo)] + list(zip(xs, fs)) + [(hi, fhi)]
-        # scan from the xb end for the first sign change
-        for j in range(len(pts) - 1, 0, -1):
-            (x0, f0), (x1, f1) = pts[j - 1], pts[j]
-            if f1 == 0:
-                return x1, rounds, funcalls
-            if f0 == 0:
-                return x0, rounds, funcalls
-            if _signbit(f0) != _signbit(f1):
-                lo, flo, hi, fhi = x0, f0, x1, f1
-                break
-        else:                                   # NaNs: cannot narrow any further
-            break
+        if any(math.isnan(f) or f == 0 for _, f in pts):
+            return None
+        changes = [j for j in range(1, len(pts)) if _signbit(pts[j - 1][1]) != _signbit(pts[j][1])]
+        if len(changes) != 1:
+            return None
+        j = changes[0]
+        (lo, flo), (hi, fhi) = pts[j - 1], pts[j]
         if rounds > 60:
-            break
-    root = lo - flo * (hi - lo) / (fhi - flo) if fhi != flo else 0.5 * (lo + hi)
-    return root, rounds, funcalls
+            return None
+    if fhi == flo:
+        return None
+    return lo - flo * (hi - lo) / (fhi - flo), rounds, funcalls
 
 
 def chi2_search_gen(npts, multisection=0):
@@ -132,7 +132,8 @@ def chi2_search_gen(npts, multisection=0):
 
     Yields log10(alpha) (or a tuple of them), receives chi^2 at that alpha (or a list).  Returns
     (outcome, alpha, info) with outcome in {'too_smooth', 'no_root', 'root'}; alpha is 0, NaN or 10**root as
-    in the reference.  multisection = K > 0 replaces the Brent iteration by K-point multisection."""
+    in the reference.  multisection = K > 0: try the guarded K-point multisection first (see multisection_gen),
+    falling back to the Brent iteration when the bracket is not provably single-rooted."""
     memo = {}
 
     def f_at(a):                       # sub-generator: memoised chi^2(a)
@@ -165,6 +166,7 @@ def chi2_search_gen(npts, multisection=0):
             break
     if not bracket:
         return 'no_root', float('nan'), dict(sf=None)
+    found = None
     if multisection:
         ms = multisection_gen(alpha, alpha0, val, val0, int(multisection))
         try:
@@ -173,7 +175,10 @@ def chi2_search_gen(npts, multisection=0):
                 chis = yield xs
                 xs = ms.send([c - nu for c in chis])
         except StopIteration as stop:
-            root, iters, _ = stop.value
+            found = stop.value                  # None: not provably a single root -> the reference's iteration
+    if found is not None:
+        root, iters, _ = found
+        finder = 'multisection'
     else:
         br = brentq_gen(alpha, alpha0, fa=val, fb=val0)
         try:
@@ -182,8 +187,9 @@ def chi2_search_gen(npts, multisection=0):
                 x = br.send((yield from f_at(x)) - nu)
         except StopIteration as stop:
             root, iters, _ = stop.value
+        finder = 'brentq'
     return 'root', float(np.power(10., root)), dict(sf=sf_used, bracket=(alpha, alpha0), log10_alpha=root,
-                                                     iterations=iters)
+                                                     iterations=iters, finder=finder)
 
 
 def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):

@@ -209,8 +209,9 @@ class FitEngine(object):
 
         * integer log10(alpha) - the bracket walk - are solved cold, except (full launches only) the far tail
           alpha <= 1e-31, which is solved in the record's alpha -> 0 eigenbasis;
-        * the first non-integer request of a record (Brent's first iterate) is solved cold *with eigenvectors*,
-          which sets up the record's rotated system; later iterates use it."""
+        * the first non-integer request of a record (Brent's first iterate, or the middle sample of a
+          multisection round) is solved cold *with eigenvectors*, which sets up the record's rotated system;
+          all other root-finder requests use it."""
         rec = np.ascontiguousarray(rec, dtype=np.int32)
         log10a = np.asarray(log10a, dtype=np.float64)
         B, N = len(rec), self.N
@@ -219,13 +220,25 @@ class FitEngine(object):
             import time
             t_tr = time.perf_counter()
         is_int = log10a == np.floor(log10a)
-        if not self.warm_enabled() or len(set(rec[~is_int].tolist())) != int((~is_int).sum()):
+        if not self.warm_enabled():
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
         walkwarm = is_int & (log10a <= self.WALK_WARM_BELOW) if self.walk_warm_enabled() else np.zeros(B, dtype=bool)
-        warm = np.array([(not i) and (r in self._warm_slot) for r, i in zip(rec.tolist(), is_int.tolist())], dtype=bool)
-        prep = (~is_int) & (~warm)
+        # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
+        # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
+        warm = np.zeros(B, dtype=bool)
+        prep = np.zeros(B, dtype=bool)
+        by_rec = {}
+        for j in np.nonzero(~is_int)[0].tolist():
+            by_rec.setdefault(int(rec[j]), []).append(j)
+        for r, js in by_rec.items():
+            if r in self._warm_slot:
+                warm[js] = True
+            else:
+                jm = js[len(js) // 2]
+                prep[jm] = True
+                warm[[j for j in js if j != jm]] = True
         cold = is_int & (~walkwarm)
         order = np.concatenate([np.nonzero(cold)[0], np.nonzero(walkwarm)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
         nc, nww, npre, nw = int(cold.sum()), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
@@ -287,11 +300,16 @@ class FitEngine(object):
         mode = os.environ.get('VINTERP_ROOT', 'auto')
         if mode == 'brent':
             return 0
-        # opt-in only: chi^2(alpha) - nu is not monotone (the curvature matrix is indefinite) and can cross zero
-        # several times inside one unit bracket; Brent's iterate sequence decides which root the reference
-        # returns (measured on the screened MAXK=8, MAXL=2 fixture: roots at -28.4698 and -28.0745 in [-29,-28]),
-        # so any other root finder breaks parity.  Multisection is kept for latency experiments.
-        if mode == 'multisection':
+        # chi^2(alpha) - nu is not monotone (the curvature matrix is indefinite) and can cross zero several times
+        # inside one unit bracket; Brent's iterate sequence decides which root the reference returns (measured on
+        # the screened MAXK=8, MAXL=2 fixture: roots at -28.4698 and -28.0745 in [-29,-28]).  The multisection of
+        # alpha_search.multisection_gen is therefore GUARDED: it proceeds only while each round's dense sampling
+        # shows exactly one sign change and otherwise hands the bracket back to the exact Brent iteration.
+        # It pays when the GPU is otherwise idle (few records: ~15 dependent solves become 3 batched rounds); a
+        # refused round costs one launch (measured at N = 144, where the indefinite curvature matrix puts poles of
+        # chi^2 inside most brackets and the guard refuses: T = 1  38.0 vs 39.4 ms, T = 2  84 vs 94, T = 8  121 vs
+        # 117, T = 16  153 vs 145 - the refused round also sets up the rotated system Brent then uses).
+        if mode == 'multisection' or self.T <= 4:
             return int(max(15, min(255, 256 // max(1, self.T) - 1)))
         return 0
 

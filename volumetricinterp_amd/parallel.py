@@ -176,6 +176,8 @@ class Comm(object):
 
         def work():
             result['rc'] = _lib.lib.vi_rccl_init(self.ctx.handle, self.world, self.rank, ident)
+            err = _lib.lib.vi_last_error()           # thread-local in the library: read it on this thread
+            result['err'] = err.decode('utf-8', 'replace') if err else ''
 
         ok = False
         if len(ident) == 128:
@@ -188,9 +190,8 @@ class Comm(object):
         oks = self.grp.allgather(b'1' if ok else b'0')
         self.rccl_ready = all(o == b'1' for o in oks)
         if not self.rccl_ready:
-            err = _lib.lib.vi_last_error()
             self.notes.append('RCCL unavailable (%s); shared parameters go over the control socket'
-                              % (err.decode('utf-8', 'replace') if err else 'unknown'))
+                              % (result.get('err') or 'failed on another rank'))
 
     # ------------------------------------------------------------------------------------------
     def broadcast_arrays(self, arrays, src=0):
