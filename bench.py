@@ -162,12 +162,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ctx.solve_timing(1)            # one HIP event pair around every eigen-solve kernel launch of the timed steps
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(record=True)
     barrier()
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+    st = ctx.solve_timing(0)
 
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
@@ -202,6 +204,18 @@ def main():
                                  'at ~3.0 kflop/point' % (EVAL_FLOPS_PER_POINT * Q * T / (ev * 1e-3) / 1e12
                                                           / FP64_VALU_PEAK_TF, FP64_VALU_PEAK_TF)},
         }
+        # the kernel the step actually spends its time in (latency-bound small-matrix
+        # factorisations, neither HBM nor MFMA): one 512-thread workgroup = one CU per system, so a single-record
+        # step can occupy 1 of 256 CUs during the ~15 dependent root-finder solves
+        if st['timed']:
+            flops = 10. * N**3 * st['systems'] * st['timed'] / max(1, st['launches'])
+            out['fit_kernel'] = {
+                'kernel': 'k_jacobi_solve<5>', 'launches_per_step': st['launches'] / args.steps,
+                'systems_per_step': st['systems'] / args.steps, 'avg_launch_ms': st['total_ms'] / st['timed'],
+                'max_launch_ms': st['max_ms'], 'ms_per_step': st['total_ms'] / st['timed'] * st['launches'] / args.steps,
+                'share_of_step': st['total_ms'] / st['timed'] * st['launches'] / (elapsed * 1e3),
+                'bound': 'LDS-resident eigen-solve, one CU per system (latency-bound at 1 record)',
+                'achieved_gflops': flops / (st['total_ms'] * 1e-3) / 1e9, 'flops_model': '10 N^3 per solve (SURVEY 8d F2)'}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
         elif world == 1:

@@ -128,6 +128,12 @@ int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* 
 /* device time (ms) of the evaluation kernel launches of the last vi_eval_f64 call on this context, from HIP
  * events recorded on the context's stream around them (the preparation kernels are excluded) */
 int  vi_eval_kernel_ms(vi_ctx* ctx, double* ms);
+/* device time of the eigen-solve kernel launches (the kernel the fit spends its time in), from one HIP event pair
+ * per launch on the context's stream.  enable = 1 starts / resets recording, 0 stops it, -1 only reads; the
+ * outputs (each may be NULL) describe the period since the last reset: launches, systems solved, number of
+ * launches whose duration is included (the 128 most recent at most), their summed and maximal duration (ms). */
+int  vi_solve_timing(vi_ctx* ctx, int enable, int64_t* launches, int64_t* systems, int64_t* timed,
+                     double* total_ms, double* max_ms);
 /* host-pointer convenience form of the same call */
 int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const double* h_lon,
                       const double* h_alt, int64_t T, const double* h_C,

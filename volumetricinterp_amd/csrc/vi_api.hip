@@ -68,6 +68,9 @@ extern "C" void vi_ctx_destroy(vi_ctx* c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
+    for (int i = 0; i < vi_ctx::NSOLVE_EV; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (c->evs[i][j]) (void)hipEventDestroy(c->evs[i][j]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -180,6 +183,48 @@ extern "C" int vi_eval_kernel_ms(vi_ctx* c, double* ms)
     float f = 0.f;
     VI_HIP(hipEventElapsedTime(&f, c->evk0, c->evk1));
     *ms = (double)f;
+    return VI_OK;
+}
+
+// Timing of the eigen-solve kernel (k_jacobi_solve), the kernel the fit spends its time in: enable = 1 starts
+// (and resets) recording of one HIP event pair per launch on the context's stream; a later call returns the
+// number of launches and systems since then and the summed / maximal launch duration of the (at most 128 most
+// recent) recorded launches.  enable = -1 only reads.  Any output pointer may be NULL.
+extern "C" int vi_solve_timing(vi_ctx* c, int enable, int64_t* launches, int64_t* systems, int64_t* timed,
+                               double* total_ms, double* max_ms)
+{
+    VI_REQUIRE(c, "null context");
+    VI_HIP(hipSetDevice(c->device));
+    if (c->solve_timing) {
+        VI_HIP(hipStreamSynchronize(c->stream));
+        const long long n = c->solve_launches < vi_ctx::NSOLVE_EV ? c->solve_launches : vi_ctx::NSOLVE_EV;
+        double tot = 0., mx = 0.;
+        for (long long i = 0; i < n; ++i) {
+            float f = 0.f;
+            VI_HIP(hipEventElapsedTime(&f, c->evs[i][0], c->evs[i][1]));
+            tot += f;
+            if (f > mx) mx = f;
+        }
+        if (launches) *launches = c->solve_launches;
+        if (systems) *systems = c->solve_systems;
+        if (timed) *timed = n;
+        if (total_ms) *total_ms = tot;
+        if (max_ms) *max_ms = mx;
+    } else {
+        if (launches) *launches = 0;
+        if (systems) *systems = 0;
+        if (timed) *timed = 0;
+        if (total_ms) *total_ms = 0.;
+        if (max_ms) *max_ms = 0.;
+    }
+    if (enable >= 0) {
+        if (enable && !c->evs[0][0])
+            for (int i = 0; i < vi_ctx::NSOLVE_EV; ++i)
+                for (int j = 0; j < 2; ++j) VI_HIP(hipEventCreate(&c->evs[i][j]));
+        c->solve_timing = enable != 0;
+        c->solve_launches = 0;
+        c->solve_systems = 0;
+    }
     return VI_OK;
 }
 

@@ -444,9 +444,16 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
     // abs_floor: the systems are scaled to max|X| in [1, 2).  Cold solves pass 1e-22: off-diagonal elements
     // below it cannot move any kept eigenvalue (|lambda| > eps * max|lambda|) by more than 1e-6 of itself.
     // Warm solves pass 1e-16: the rotated system D1 + alpha D2 carries formation errors of N*eps anyway.
+    const int slot = (int)(c->solve_launches % vi_ctx::NSOLVE_EV);
+    if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[slot][0], c->stream));
     hipLaunchKernelGGL(k_jacobi_solve<IT>, dim3((unsigned)B), dim3(JBS), shm, c->stream, N, d_X, d_scl, d_y, d_rec,
                        rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround);
     VI_HIP(hipGetLastError());
+    if (c->solve_timing) {
+        VI_HIP(hipEventRecord(c->evs[slot][1], c->stream));
+        c->solve_launches += 1;
+        c->solve_systems += B;
+    }
     return VI_OK;
 }
 
