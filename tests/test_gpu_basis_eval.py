@@ -167,6 +167,32 @@ def test_eval_many_timesteps_and_ragged_sizes():
     assert es.evaluate_coeffs(C, lat[:0], lon[:0], alt[:0]).shape == (22, 0)
 
 
+@pytest.mark.parametrize('tag,maxk,maxl', [('default', 4, 6), ('k8l2', 8, 2)])
+def test_eval_matrix_core_tiles_vs_oracle(tag, maxk, maxl):
+    """T = 117 rows on one grid: 64 + 32 + 16 timesteps through the matrix-core kernel (k_eval_sph_mfma, tiles of
+    4 / 2 / 1 x 16), the last 5 through the VALU kernels; Q = 1003 is not a multiple of 16 or 64; against the oracle's
+    basis matrix, with the hull mask, and with the matrix-core path switched off."""
+    import oracle
+    f, es = _estimate(tag)
+    rng = np.random.default_rng(21)
+    Q, T = 1003, 117
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
+    N = f['Coeffs'].shape[1]
+    C = rng.standard_normal((T, N)) * np.abs(np.nan_to_num(f['Coeffs'][0])).max()
+    out = es.evaluate_coeffs(C, lat, lon, alt, check_hull=False)
+    A = oracle.SphHarmLagOracle(maxk=maxk, maxl=maxl).basis(lat, lon, alt)
+    ref = C @ A.T
+    assert out.shape == (T, Q)
+    for t in range(T):
+        assert rel(out[t], ref[t]) <= 1e-10, t
+    outh = es.evaluate_coeffs(C, lat, lon, alt, check_hull=True)
+    chk = oracle.check_hull(f['hull_vert'], lat[:150], lon[:150], alt[:150])
+    assert np.array_equal(np.isfinite(outh[3, :150]), chk) and np.array_equal(np.isfinite(outh[116, :150]), chk)
+    ok = np.isfinite(outh)
+    assert np.array_equal(ok, np.broadcast_to(ok[0], ok.shape))
+    assert rel(outh[ok], out[ok]) == 0.0                                # same kernel, masked stores only
+
+
 def test_rbf_estimate_vs_oracle():
     import oracle
     from volumetricinterp_amd.estimate import Estimate

@@ -8,75 +8,11 @@
 // a wave share (recurrence coefficients, coefficient tiles) is addressed wave-uniformly so it is
 // served by the scalar data path / LDS broadcast and never costs per-lane HBM traffic.
 #include "vi_common.h"
+#include "vi_sph_device.h"
 
 #include <cstdlib>
 
 namespace {
-
-constexpr int BLOCK = 256;
-constexpr double WGS84_A = 6378137.0;
-constexpr double WGS84_B = 6356752.31424518;
-constexpr double DEG2RAD = 0.017453292519943295;   // pi/180, the constant np.radians multiplies by
-
-struct Geom {
-    double X, Y, Z;          // ECEF, metres
-    double x, s;             // cos(theta), sin(theta) of the rotated colatitude
-    double cphi, sphi;       // cos/sin of the rotated azimuth
-    double z;                // 100 (r/RE - 1)
-    double Rx, Ry;           // rotated equatorial components (for atan2 in vi_transform)
-};
-
-// pymap3d.geodetic2ecef (WGS84 closed form), called at sphharmlag.py:351 / radbasfun.py:253
-__device__ __forceinline__ void geodetic2ecef(double lat, double lon, double alt, double& X, double& Y, double& Z)
-{
-    double sl, cl, so, co;
-    sincos(lat * DEG2RAD, &sl, &cl);
-    sincos(lon * DEG2RAD, &so, &co);
-    const double a2 = WGS84_A * WGS84_A, b2 = WGS84_B * WGS84_B;
-    const double Nn = a2 / sqrt(a2 * cl * cl + b2 * sl * sl);
-    const double ba = WGS84_B / WGS84_A;
-    X = (Nn + alt) * cl * co;
-    Y = (Nn + alt) * cl * so;
-    Z = (Nn * (ba * ba) + alt) * sl;
-}
-
-// sphharmlag.py:345-359: Rodrigues rotation about k = (kx, ky, 0) by +theta0 (sign as written, F3)
-__device__ __forceinline__ Geom sph_geom(const SphDev& M, double lat, double lon, double alt)
-{
-    Geom g;
-    geodetic2ecef(lat, lon, alt, g.X, g.Y, g.Z);
-    const double kd = M.kx * g.X + M.ky * g.Y;
-    const double omc = 1.0 - M.rc;
-    const double Rx = g.X * M.rc + (M.ky * g.Z) * M.rs + M.kx * kd * omc;
-    const double Ry = g.Y * M.rc + (-M.kx * g.Z) * M.rs + M.ky * kd * omc;
-    const double Rz = g.Z * M.rc + (M.kx * g.Y - M.ky * g.X) * M.rs;
-    const double rho2 = Rx * Rx + Ry * Ry;
-    const double r = sqrt(rho2 + Rz * Rz);
-    g.x = Rz / r;
-    g.s = sqrt(1.0 - g.x * g.x);          // scipy's lpmv forms (1-x^2)^(m/2) from x
-    const double rho = sqrt(rho2);
-    const bool pole = !(rho > 0.0);
-    g.cphi = pole ? 1.0 : Rx / rho;       // arctan2(0,0) = 0
-    g.sphi = pole ? 0.0 : Ry / rho;
-    g.z = 100.0 * (r / M.RE - 1.0);
-    g.Rx = Rx;
-    g.Ry = Ry;
-    return g;
-}
-
-// 2F1(a,b;c;zz) series with host-tabulated term ratios q[i] = (a+i)(b+i)/((c+i)(i+1)); the exit test
-// is wave-uniform so the table stays on the scalar path.
-__device__ __forceinline__ double hyp_series(const double* __restrict__ q, int nterms, double zz)
-{
-    double r = 1.0, sum = 1.0;
-    for (int i = 0; i < nterms; ++i) {
-        const double qi = q[i];
-        r *= qi * zz;
-        sum += r;
-        if (__all(fabs(r) <= 1e-17 * fabs(sum))) break;
-    }
-    return sum;
-}
 
 // The shared per-point engine.  Sink::consume(l, cur[], cm[], sm[]) is called once per degree l with
 // cur[m] = (normalised) P_{nu_l}^m(cos theta), m = 0..l.
@@ -130,20 +66,6 @@ __device__ __forceinline__ void sph_point(const SphDev& M, const Geom& g, Sink& 
             if (l >= 0) sink.template consume<LCAP>(l, cur, cm, sm);
         }
     }
-}
-
-// scipy.special.eval_laguerre(k, z), k = 0..maxk-1, by the three-term recurrence (sphharmlag.py:141)
-template <int KCAP>
-__device__ __forceinline__ void laguerre(int maxk, double z, double* Lk)
-{
-    Lk[0] = 1.0;
-    if (KCAP > 1) Lk[1] = 1.0 - z;
-#pragma unroll
-    for (int k = 1; k + 1 < KCAP; ++k) {
-        const double inv = 1.0 / (double)(k + 1);
-        Lk[k + 1] = ((2.0 * k + 1.0 - z) * Lk[k] - (double)k * Lk[k - 1]) * inv;
-    }
-    (void)maxk;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,8 +667,8 @@ int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double
     }
     // timestep tiles of 16 / 4 / 1: the basis is recomputed once per tile, so a wide tile amortises it and the
     // contraction (2N flop per point-timestep) dominates.  Measured at 128^3, N = 144: 1.4e10 / 3.9e10 / 6.2e10
-    // point-timesteps/s for tiles of 1 / 4 / 16 (a tile of 8 is slower than 16).  fp64 MFMA has the same peak as the
-    // fp64 VALU on gfx950 (78.6 TF), so a GEMM reformulation of the contraction would not raise the ceiling.
+    // point-timesteps/s for tiles of 1 / 4 / 16 (a tile of 8 is slower than 16).  Whole tiles of 16 timesteps normally
+    // never get here: vi_eval_mfma.hip contracts them on the matrix cores (1.2e11).
     const bool wide_ok = shm(16) <= 60 * 1024;
     int64_t t = 0;
     while (t < T) {
@@ -780,6 +702,11 @@ struct EvalTimer {
         if (c->evk_valid) c->evk_valid = hipEventRecord(c->evk1, c->stream) == hipSuccess;
     }
 };
+
+}  // namespace
+int vi_eval_sph_mfma(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
+                     const double* Cp, const unsigned char* hull, int F, double* out, int64_t* done);
+namespace {
 
 bool use_fast_eval()
 {
@@ -906,9 +833,19 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         VI_HIP(hipGetLastError());
         const int L = m->sph.maxl, K = m->sph.maxk;
         EvalTimer timer(m->ctx);
+        // whole tiles of 16 timesteps go to the matrix-core kernel (vi_eval_mfma.hip); the rest to the VALU kernels
+        int64_t done = 0;
+        if (use_fast_eval()) {
+            const int rc = vi_eval_sph_mfma(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, (int)F, d_out, &done);
+            if (rc != VI_OK) return rc;
+            if (done == T) return VI_OK;
+        }
+        const int64_t Tr = T - done;
+        const double* coef = m->d_coef + done * N;
+        double* outp = d_out + done * Q;
         if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
 #define VI_FAST(LL, KK) \
-    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out)
+    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp)
             VI_FAST(6, 4);
             VI_FAST(2, 8);
             VI_FAST(3, 4);
@@ -919,11 +856,11 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
 #undef VI_FAST
         }
         if (L <= 6 && K <= 4)
-            return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
+            return launch_eval_sph<6, 4>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp);
         if (L <= 12 && K <= 8)
-            return launch_eval_sph<12, 8>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
+            return launch_eval_sph<12, 8>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp);
         if (L <= 24 && K <= 16)
-            return launch_eval_sph<24, 16>(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, F, hull_tol, d_out);
+            return launch_eval_sph<24, 16>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp);
         vi_set_error("vi_eval_f64: order MAXL=%d MAXK=%d beyond the compiled limits (24, 16)", L, K);
         return VI_ERR_UNSUPPORTED;
     }
