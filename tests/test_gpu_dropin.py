@@ -106,6 +106,60 @@ def test_config_to_hdf5_to_estimate(tmp_path):
     assert rel(it2.Coeffs[1], it.Coeffs[2]) <= 1e-7
 
 
+def _write_amisr(path, f, T):
+    from volumetricinterp_amd import synth, h5io
+    nb, nr = synth.GEOM_C1
+    with h5io.H5File(path, 'w') as h5:
+        for g in ('/Time', '/Geomag', '/FittedParams', '/FittedParams/FitInfo'):
+            h5.create_group(g)
+        h5.create_array('/Time/UnixTime', f['utime'][:T])
+        h5.create_array('/Geomag/Altitude', f['alt'].reshape(nb, nr))
+        h5.create_array('/Geomag/Latitude', f['lat'].reshape(nb, nr))
+        h5.create_array('/Geomag/Longitude', f['lon'].reshape(nb, nr))
+        h5.create_array('/FittedParams/FitInfo/chi2', np.ones((T, nb, nr)))
+        h5.create_array('/FittedParams/FitInfo/fitcode', np.ones((T, nb, nr), dtype=np.int64))
+        h5.create_array('/FittedParams/IonMass', np.array([16.]))
+        h5.create_array('/FittedParams/Ne', f['value'][:T].reshape(T, nb, nr))
+        h5.create_array('/FittedParams/dNe', f['error'][:T].reshape(T, nb, nr))
+
+
+def test_cli_two_ranks_equal_one(tmp_path):
+    """The command line entry point under a 2-rank launch (both ranks share this box's one GPU; the RCCL
+    communicator refuses the duplicate device and the shared parameters go over the control socket) writes the same
+    coefficient file as the single-process run."""
+    import subprocess
+    import sys
+    from volumetricinterp_amd.estimate import Estimate
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = load_golden('fit_k8l2')
+    T = 4
+    inp = str(tmp_path / 'amisr.h5')
+    _write_amisr(inp, f, T)
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / ('coeffs%d.h5' % world))
+        cfg = str(tmp_path / ('config%d.ini' % world))
+        with open(cfg, 'w') as fh:
+            fh.write(CFG.format(inp=inp, out=out))
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT='29517', PYTHONPATH=REPO, VINTERP_RDV_PATH=str(tmp_path / ('rdv%d.sock' % world)))
+            procs.append(subprocess.Popen([sys.executable, '-m', 'volumetricinterp_amd.run_volumetricinterp', cfg],
+                                          env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p_ in procs:
+            o, _ = p_.communicate(timeout=600)
+            assert p_.returncode == 0, o.decode()
+        outs.append(Estimate(out))
+    one, two = outs
+    assert one.Coeffs.shape == two.Coeffs.shape == (T, 32)
+    np.testing.assert_array_equal(one.time, two.time)
+    for t in range(T):
+        # 2 records per rank instead of 4: the guarded multisection samples other abscissae (K = 256 // T - 1)
+        assert rel(two.Coeffs[t], one.Coeffs[t]) <= 1e-7, t
+        assert rel(two.Coeffs[t], f['Coeffs'][t]) <= 1e-6, t
+
+
 def test_unsupported_regularisation_name_raises_keyerror(tmp_path):
     from volumetricinterp_amd import Interpolate
     cfgfile = str(tmp_path / 'config.ini')

@@ -159,15 +159,28 @@ class Interpolate(object):
         self.hull_vert = R_cart[chull.vertices]
 
     # interpolate.py:472-579
-    def calc_coeffs(self, starttime=None, endtime=None):
-        print('Evaluating Regularization matricies.  This may take a few minutes.')
+    def calc_coeffs(self, starttime=None, endtime=None, comm=None):
+        """interpolate.py:472-579.  With a multi-rank `comm` (parallel.Comm; one process per GPU) the records are
+        sharded in contiguous blocks: rank 0 evaluates the regularisation matrices and broadcasts them, every rank
+        fits its block, and the rows are gathered so that every rank (rank 0 writes the file) holds the full result.
+        The record loop of the reference carries no state between records (interpolate.py:511), so the sharded
+        result equals the single-process result row for row."""
+        multi = comm is not None and comm.world > 1
         reg_matricies = {}
-        for reg in self.regularization_list:
-            try:
-                reg_matricies[reg] = self.model.eval_reg_matricies[reg]()
-            except KeyError as e:
-                print('WARNING: The model {} does not support {} regularization!'.format(self.model_name, reg))
-                raise e
+        if not multi or comm.rank == 0:
+            print('Evaluating Regularization matricies.  This may take a few minutes.')
+            for reg in self.regularization_list:
+                try:
+                    reg_matricies[reg] = self.model.eval_reg_matricies[reg]()
+                except KeyError as e:
+                    print('WARNING: The model {} does not support {} regularization!'.format(self.model_name, reg))
+                    if multi:
+                        comm.broadcast_arrays({'__unsupported__': np.zeros(1)})
+                    raise e
+        if multi:
+            reg_matricies = comm.broadcast_arrays(reg_matricies)
+            if '__unsupported__' in reg_matricies:
+                raise KeyError('regularization not supported by model {}'.format(self.model_name))
 
         utime, lat, lon, alt, value, error = self.read_datafile(self.filename)
         self.compute_hull(lat, lon, alt)
@@ -180,7 +193,26 @@ class Interpolate(object):
             value = value[idx]
             error = error[idx]
 
-        res = self.fit_records(lat, lon, alt, value, error, reg_matricies)
+        if not multi:
+            res = self.fit_records(lat, lon, alt, value, error, reg_matricies)
+        else:
+            from .parallel import shard_bounds
+            T, N = value.shape[0], self.model.nbasis
+            lo, hi = shard_bounds(T, comm.rank, comm.world)
+            names = list(self.regularization_list)
+            if hi > lo:
+                loc = self.fit_records(lat, lon, alt, value[lo:hi], error[lo:hi], reg_matricies)
+                par = np.array([[p[n] for n in names] for p in loc['reg_params']], dtype=np.float64).reshape(hi - lo, len(names))
+            else:
+                loc = dict(Coeffs=np.zeros((0, N)), Covariance=np.zeros((0, N, N)), chi_sq=np.zeros(0))
+                par = np.zeros((0, len(names)))
+            res = dict(Coeffs=comm.gather_rows(loc['Coeffs'], T), Covariance=comm.gather_rows(loc['Covariance'], T),
+                       chi_sq=comm.gather_rows(np.asarray(loc['chi_sq'], dtype=np.float64).reshape(-1, 1), T)[:, 0])
+            if names:
+                par = comm.gather_rows(par, T)
+                res['reg_params'] = [dict(zip(names, row.tolist())) for row in par]
+            else:
+                res['reg_params'] = [dict() for _ in range(T)]
         self.time = utime
         self.Coeffs = res['Coeffs']
         self.Covariance = res['Covariance']

@@ -4,6 +4,14 @@ Mirror of the reference CLI ``volumetricinterp/run_volumetricinterp.py:14-35`` (
 ``volumetricinterp``) for the fit path; ``--validate`` (cartopy plots, validate.py) is out of scope here.
 
     python -m volumetricinterp_amd.run_volumetricinterp config.ini
+
+Multi-GPU (one node): launch one process per GPU with the usual launcher,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        -m volumetricinterp_amd.run_volumetricinterp config.ini
+
+Every rank fits a contiguous block of the file's records on GPU LOCAL_RANK; rank 0 broadcasts the regularisation
+matrices (RCCL) and writes the coefficient file (parallel.py).
 """
 import argparse
 import sys
@@ -21,6 +29,22 @@ def main(argv=None):
               file=sys.stderr)
         return 2
     from .interpolate import Interpolate
+    from .parallel import Comm, env_rank
+    rank, world, local_rank = env_rank()
+    if world > 1:
+        import os
+        from . import _lib
+        ctx = _lib.get_context(local_rank)
+        comm = Comm(backend=os.environ.get('VINTERP_DIST_BACKEND', 'rccl'), ctx=ctx)
+        try:
+            interp = Interpolate(args.config_file, ctx=ctx)
+            interp.calc_coeffs(comm=comm)
+            if rank == 0:
+                interp.saveh5()
+            comm.barrier()
+        finally:
+            comm.close()
+        return 0
     interp = Interpolate(args.config_file)
     interp.calc_coeffs()
     interp.saveh5()
