@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--grid', type=int, default=128, help='query grid edge (128 -> 128^3 points)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eval-many', action='store_true', help='skip the secondary many-timesteps evaluation figure')
     return ap.parse_args()
 
 
@@ -171,6 +172,28 @@ def main():
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     st = ctx.solve_timing(0)
 
+    # ---- secondary figure (not part of `value`): many timesteps on the same grid (SURVEY 8d row E2, configs[3]) ----
+    many = None
+    if rank == 0 and not args.no_eval_many:
+        Tm = 64
+        dCm = ctx.to_device(np.random.default_rng(3).standard_normal((Tm, N)))
+        dom = ctx.empty((Tm, Q))
+        best = float('inf')
+        for _ in range(3):
+            _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tm, dCm.ptr, None, 0, 0., dom.ptr),
+                       'vi_eval_f64')
+            kms = C.c_double(0.)
+            _lib.check(_lib.lib.vi_eval_kernel_ms(ctx.handle, C.byref(kms)), 'vi_eval_kernel_ms')
+            best = min(best, kms.value)
+        dom.free()
+        dCm.free()
+        many = {'kernel': 'k_eval_sph_mfma<6,1,2> (v_mfma_f64_16x16x4)', 'timesteps': Tm, 'points': Q, 'ms': best,
+                'point_timesteps_per_sec': Q * Tm / (best * 1e-3), 'bound': 'mfma',
+                'achieved': 2. * N * Q * Tm / (best * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': 2. * N * Q * Tm / (best * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                'note': 'algorithmic flops 2N per point-timestep (the contraction only; the recurrence is VALU work on '
+                        'top); fp64 MFMA and fp64 VALU share one 78.6 TF peak on gfx950 and do not co-execute'}
+
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
         traffic = None                 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
@@ -216,6 +239,8 @@ def main():
                 'share_of_step': st['total_ms'] / st['timed'] * st['launches'] / (elapsed * 1e3),
                 'bound': 'LDS-resident eigen-solve, one CU per system (latency-bound at 1 record)',
                 'achieved_gflops': flops / (st['total_ms'] * 1e-3) / 1e9, 'flops_model': '10 N^3 per solve (SURVEY 8d F2)'}
+        if many is not None:
+            out['eval_many_timesteps'] = many
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
         elif world == 1:
