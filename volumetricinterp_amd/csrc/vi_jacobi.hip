@@ -25,6 +25,9 @@
 //    truncation is going to drop anyway; a sweep without rotations ends the iteration.
 #include "vi_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 #ifdef VI_STAMPS
 // diagnostic build only (make STAMPS=1): per-phase cycle sums of workgroup 0, wave 0
 __device__ unsigned long long g_jacobi_stamps[8];
@@ -383,6 +386,80 @@ __global__ __launch_bounds__(JBS) void k_jacobi_vectors(int N, const double2* __
     }
 }
 
+// Latency variant for FEW systems (a single record's prepare / final solve): one WAVE per strip of CPW columns, no
+// workgroup barrier at all - the DS operations of one wave execute in order, so the write -> read hand-over between
+// consecutive rounds needs only a wave fence (the same replay wave 0 of k_jacobi_solve runs for C = V g).  Lane l
+// owns pairs l and l + 64; the (c, s) of a round are loaded once and applied to the CPW columns of the strip.
+// N / CPW independent waves per system spread over as many CUs.  Even N <= 256 only.
+template <int CPW>
+__global__ __launch_bounds__(64) void k_jacobi_vectors_wave(int N, const double2* __restrict__ rotlog, int64_t log_stride,
+                                                            const int* __restrict__ nround_in, double* __restrict__ Vout)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int m = N >> 1;
+    double* buf0 = reinterpret_cast<double*>(lds_raw);               // [N][CPW]
+    double* buf1 = buf0 + (size_t)N * CPW;
+    const int lane = threadIdx.x;
+    const int64_t sys = blockIdx.x;
+    const int c0 = blockIdx.y * CPW;
+    const double2* logp = rotlog + sys * log_stride;
+    const int64_t nround = nround_in[sys];
+    for (int i = lane; i < N * CPW; i += 64) {
+        const int s = i / CPW, c = i - s * CPW;
+        buf0[i] = (s == c0 + c) ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PF = 8;                               // rounds of (c, s) prefetched per batch
+    const int P0 = lane, P1 = lane + 64;
+    const bool has0 = P0 < m, has1 = P1 < m;
+    const int p0 = 2 * P0, p1 = 2 * P0 + 1, q0 = 2 * P1, q1 = 2 * P1 + 1;
+    const int n0 = slot_next(has0 ? p0 : 0, m) * CPW, n1 = slot_next(has0 ? p1 : 1, m) * CPW;
+    const int m0 = slot_next(has1 ? q0 : 0, m) * CPW, m1 = slot_next(has1 ? q1 : 1, m) * CPW;
+    double* yc = buf0;
+    double* yo = buf1;
+    for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
+        const int nb = r1 >= PF ? PF : (int)r1;
+        double2 pf0[PF], pf1[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u < nb) {
+                if (has0) pf0[u] = logp[(r1 - 1 - u) * m + P0];
+                if (has1) pf1[u] = logp[(r1 - 1 - u) * m + P1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u < nb) {
+                if (has0) {
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) {
+                        const double gp = yc[n0 + c], gq = yc[n1 + c];
+                        yo[p0 * CPW + c] = pf0[u].x * gp + pf0[u].y * gq;
+                        yo[p1 * CPW + c] = -pf0[u].y * gp + pf0[u].x * gq;
+                    }
+                }
+                if (has1) {
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) {
+                        const double gp = yc[m0 + c], gq = yc[m1 + c];
+                        yo[q0 * CPW + c] = pf1[u].x * gp + pf1[u].y * gq;
+                        yo[q1 * CPW + c] = -pf1[u].y * gp + pf1[u].x * gq;
+                    }
+                }
+                double* t = yc; yc = yo; yo = t;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    double* Vo = Vout + sys * (int64_t)N * N;
+    for (int i = lane; i < N * CPW; i += 64) {
+        const int c = i / N, s = i - c * N;                          // s fastest: contiguous stores
+        if (c0 + c < N) Vo[(int64_t)(c0 + c) * N + slot_orig0(s, m)] = yc[s * CPW + c];
+    }
+}
+
 }  // namespace
 
 #ifdef VI_STAMPS
@@ -497,8 +574,37 @@ static int launch_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int ma
 
 int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
 {
+    // very few systems (one record's prepare / final solve): one barrier-free wave per column (measured at N = 144,
+    // one system: 0.62 ms for 1 column per wave, 0.94 for 2, 1.8 for 4; the workgroup kernel below takes 1.47 ms);
     // few systems: narrow column blocks spread one system over more CUs (latency); many systems: wide blocks
     // re-read the rotation log fewer times (throughput)
+    static int wave_ok = -1;
+    if (wave_ok < 0) {
+        const char* e = getenv("VINTERP_VECTORS");
+        wave_ok = (e && !strcmp(e, "block")) ? 0 : 1;
+    }
+    static int cpw = -1;
+    if (cpw < 0) {
+        const char* e = getenv("VINTERP_VECTORS_CPW");
+        cpw = e ? atoi(e) : 1;
+    }
+    if (wave_ok && N <= 256 && (N % 2) == 0 && B * ((N + cpw - 1) / cpw) <= 2 * c->n_cu) {
+        const int m = N / 2;
+        const int64_t log_stride = (int64_t)max_sweeps * (N - 1) * m;
+        const size_t shm = (size_t)2 * N * cpw * sizeof(double);
+        const dim3 grid((unsigned)B, (unsigned)((N + cpw - 1) / cpw));
+        if (cpw == 1)
+            hipLaunchKernelGGL(k_jacobi_vectors_wave<1>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
+                               d_nround, d_V);
+        else if (cpw == 2)
+            hipLaunchKernelGGL(k_jacobi_vectors_wave<2>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
+                               d_nround, d_V);
+        else
+            hipLaunchKernelGGL(k_jacobi_vectors_wave<4>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
+                               d_nround, d_V);
+        VI_HIP(hipGetLastError());
+        return VI_OK;
+    }
     if (B * ((N + 35) / 36) < c->n_cu / 2) return launch_vectors<12>(c, B, N, d_log, max_sweeps, d_nround, d_V);
     return launch_vectors<36>(c, B, N, d_log, max_sweeps, d_nround, d_V);
 }
