@@ -421,7 +421,9 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
     int* info = (int*)((char*)ws + (2 * nD + (size_t)B) * sizeof(double) + (d_H ? (size_t)B * N * N * sizeof(double) : 0));
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
     VI_HIP(hipGetLastError());
-    if (eig_method() >= 1) {
+    // orders beyond the in-LDS solver (N > ~200): divide and conquer.  Measured at N = 1152 (configs[4]): syevd 10.6 ms
+    // per system against 295 ms for rocSOLVER's Jacobi (syevj), which is only used when asked for (VINTERP_EIG=syevj).
+    if (eig_method() == 1) {
         int* nsweeps = info + B;
         double* resid = E;
         VI_ROCSOLVER(rocsolver_dsyevj_strided_batched(c->blas, rocblas_esort_ascending, rocblas_evect_original,

@@ -61,11 +61,25 @@ __device__ __forceinline__ Geom sph_geom(const SphDev& M, double lat, double lon
 __device__ __forceinline__ double hyp_series(const double* __restrict__ q, int nterms, double zz)
 {
     double r = 1.0, sum = 1.0;
-    for (int i = 0; i < nterms; ++i) {
-        const double qi = q[i];
-        r *= qi * zz;
+    // four terms per exit test: the ratios of a block arrive in one wide scalar load instead of four dependent ones
+    // (measured at MAXL = 12, CAP_LIM = 15: the 24 seed series were ~40 % of the evaluation kernel); the up to
+    // three terms added past convergence are below 1e-17 of the sum
+    int i = 0;
+    for (; i + 3 < nterms; i += 4) {
+        const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3];
+        r *= q0 * zz;
         sum += r;
-        if (__all(fabs(r) <= 1e-17 * fabs(sum))) break;
+        r *= q1 * zz;
+        sum += r;
+        r *= q2 * zz;
+        sum += r;
+        r *= q3 * zz;
+        sum += r;
+        if (__all(fabs(r) <= 1e-17 * fabs(sum))) return sum;
+    }
+    for (; i < nterms; ++i) {
+        r *= q[i] * zz;
+        sum += r;
     }
     return sum;
 }

@@ -293,7 +293,10 @@ class FitEngine(object):
 
     def default_prefetch(self):
         # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound),
-        # a few steps ahead for large batches (the launch is already full; don't waste solves)
+        # a few steps ahead for large batches (the launch is already full; don't waste solves).  Beyond the in-LDS
+        # solver (N > 180: rocSOLVER, ~0.15 s per N = 1152 system) every extra solve is dear: stay close to the walk.
+        if not self.warm_enabled() and self.N > 180:
+            return 4
         return int(max(8, min(102, 2048 // max(1, self.T))))
 
     def default_multisection(self):
@@ -309,7 +312,9 @@ class FitEngine(object):
         # refused round costs one launch (measured at N = 144, where the indefinite curvature matrix puts poles of
         # chi^2 inside most brackets and the guard refuses: T = 1  38.0 vs 39.4 ms, T = 2  84 vs 94, T = 8  121 vs
         # 117, T = 16  153 vs 145 - the refused round also sets up the rotated system Brent then uses).
-        if mode == 'multisection' or self.T <= 4:
+        # Only where the in-LDS solver serves the rounds: at orders beyond it (N > 180, rocSOLVER, ~0.15 s per solve
+        # at N = 1152) K extra solves per round are far dearer than Brent's dependent ones.
+        if mode == 'multisection' or (self.T <= 4 and self.warm_enabled()):
             return int(max(15, min(255, 256 // max(1, self.T) - 1)))
         return 0
 
