@@ -248,6 +248,11 @@ def main():
         real_stdout.write(json.dumps(out) + '\n')
         real_stdout.flush()
     comm.close()
+    if any('did not return' in n for n in comm.notes):
+        # a communicator bootstrap that never returned leaves a thread inside RCCL: skip the interpreter's and the
+        # runtime's finalisers, which could block on it, now that the result line is out
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
