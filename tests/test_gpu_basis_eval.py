@@ -193,6 +193,32 @@ def test_eval_matrix_core_tiles_vs_oracle(tag, maxk, maxl):
     assert rel(outh[ok], out[ok]) == 0.0                                # same kernel, masked stores only
 
 
+@pytest.mark.parametrize('maxk,maxl,cap', [(4, 3, 10.), (2, 12, 15.), (4, 6, 12.7)])
+def test_eval_matrix_core_other_orders_vs_oracle(maxk, maxl, cap):
+    """The other instantiations of the matrix-core kernel: MAXL 3 x MAXK 4 (integer degrees); MAXL 12 x MAXK 2 (a
+    Laguerre quad padded with zero coefficients; CAP_LIM 15: half-integer degrees, 2F1 seeds; at CAP_LIM 10 this order
+    overflows Kvm, F8, and every density is NaN as in the reference); and an order the kernel declines (CAP_LIM 12.7:
+    several degree groups), which must fall through to the generic kernel."""
+    import oracle
+    from volumetricinterp_amd.estimate import Estimate
+    from volumetricinterp_amd import synth
+    cfg = ('[DEFAULT]\n[MODEL]\nNAME = sphharmlag\nMAXK = %d\nMAXL = %d\nCAP_LIM = %g\nMAX_Z_INT = INF\nLATCP = 78\n'
+           'LONCP = 262\n' % (maxk, maxl, cap))
+    N = maxk * maxl * maxl
+    rng = np.random.default_rng(5)
+    Q, T = 333, 40                                             # 32 + (8 through the VALU kernels)
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
+    A = oracle.SphHarmLagOracle(maxk=maxk, maxl=maxl, cap_lim_deg=cap).basis(lat, lon, alt)
+    good = np.all(np.isfinite(A), axis=0)
+    assert np.all(good)
+    C = rng.standard_normal((T, N)) / np.maximum(np.abs(A).max(axis=0), 1e-300)
+    es = Estimate.from_arrays(C, None, synth.unix_times(T), np.zeros((4, 3)), cfg)
+    out = es.evaluate_coeffs(C, lat, lon, alt, check_hull=False)
+    ref = C[:, good] @ A[:, good].T
+    for t in range(T):
+        assert rel(out[t], ref[t]) <= 1e-10, t
+
+
 def test_rbf_estimate_vs_oracle():
     import oracle
     from volumetricinterp_amd.estimate import Estimate
