@@ -238,7 +238,10 @@ def main():
                 'max_launch_ms': st['max_ms'], 'ms_per_step': st['total_ms'] / st['timed'] * st['launches'] / args.steps,
                 'share_of_step': st['total_ms'] / st['timed'] * st['launches'] / (elapsed * 1e3),
                 'bound': 'LDS-resident eigen-solve, one CU per system (latency-bound at 1 record)',
-                'achieved_gflops': flops / (st['total_ms'] * 1e-3) / 1e9, 'flops_model': '10 N^3 per solve (SURVEY 8d F2)'}
+                'achieved_gflops': flops / (st['total_ms'] * 1e-3) / 1e9, 'flops_model': '10 N^3 per solve (SURVEY 8d F2)',
+                'peak_gflops': FP64_VALU_PEAK_TF * 1e3,
+                'frac': flops / (st['total_ms'] * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                'frac_note': 'of the whole-chip fp64 peak; a launch of B systems can occupy min(B, 256) of 256 CUs'}
         if many is not None:
             out['eval_many_timesteps'] = many
         if not args.no_cpu_baseline and world == 1:
