@@ -97,7 +97,7 @@ def test_truncated_solve_rank_deficient_indefinite():
 
 
 @pytest.mark.parametrize('root', ['auto', 'brent'])
-@pytest.mark.parametrize('name', ['fit_k8l2', 'fit_k8l2_c2'])
+@pytest.mark.parametrize('name', ['fit_k8l2', 'fit_k8l2_c2', 'fit_k8l2_psi'])
 def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
     """End to end on screened fixtures (reference self-noise < 1e-8): north-star tolerance 1e-6 on the
     coefficients, same alpha, same chi^2, covariance within 1e-5.  'auto' = guarded multisection for few records
@@ -105,7 +105,9 @@ def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
     only."""
     monkeypatch.setenv('VINTERP_ROOT', root)
     f = load_golden(name)
-    assert np.all(f['self_noise'] < 1e-8)
+    # curvature fixtures reproduce themselves to 1e-8 in the reference; the 0thorder one (Psi, positive semidefinite:
+    # chi^2 monotone, one root) to 2e-7, still inside the gate
+    assert np.all(f['self_noise'] < (1e-6 if name.endswith('psi') else 1e-8))
     regm, reg = reg_of(f)
     it = make_interp(tmp_path, str(f['cfg']))
     res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
@@ -117,6 +119,79 @@ def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
     if root == 'brent':
         # work accounting: one solve per distinct alpha (memoised, plus walk prefetch) - far fewer than the reference
         assert it.fit_stats['solves'] < int(f['evalC_calls'])
+
+
+class _PerturbedBasis(object):
+    """Oracle model whose basis carries 1e-14 relative noise: the screen tools/gen_golden.py applies to the reference
+    itself (a record whose fit moves under it is decided by rounding - truncation rank flips at the rcond threshold,
+    where LAPACK's tiny singular values are noise - and no implementation can be expected to reproduce it)."""
+
+    def __init__(self, model, seed):
+        self._m, self._rng = model, np.random.default_rng(seed)
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def basis(self, lat, lon, alt):
+        A = self._m.basis(lat, lon, alt)
+        return A * (1 + 1e-14 * self._rng.standard_normal(A.shape))
+
+
+@pytest.mark.parametrize('maxk,maxl,reg,seed', [(8, 2, 'curvature', 80), (8, 2, '0thorder', 81), (8, 2, 'curvature', 82),
+                                                 (4, 3, '0thorder', 77)])
+def test_fresh_records_vs_oracle(tmp_path, maxk, maxl, reg, seed):
+    """Parity beyond the committed fixtures: fresh geometry and records, GPU fit against the CPU oracle on identical
+    inputs.  Every record is first screened the way the fixtures were: the oracle is rerun with 1e-14 relative noise on
+    its basis and the record only counts if its coefficients move by s < 1e-5; the GPU must then agree within
+    max(1e-6, 10 s).  (Measured: at MAXK 8, MAXL 2 s is 1e-9..1e-6; at (2,3) 1e-8..1e-4, one draw of s not bounding the next, so that
+    order is not used; at (4,3) and (3,4) 1e-4..1e-2: X(alpha) there has eigenvalues a few eps * lambda_max - 4.96e-16
+    kept, 1.95e-16 dropped at the root of record 0 - which LAPACK resolves with absolute error eps * sigma_max, i.e. ~50 %
+    relative, and whose 1/lambda dominates |C|; the Jacobi solver resolves them to full relative accuracy, so GPU and
+    oracle differ by O(1..10) in |C| while chi^2 agrees.  Such orders are skipped, as the default order is in DESIGN.md
+    section 2.)"""
+    import re
+    import warnings
+    import oracle
+    from volumetricinterp_amd import synth
+    cfg = str(load_golden('fit_k8l2_psi')['cfg'])
+    cfg = re.sub(r'MAXK = \d+', 'MAXK = %d' % maxk, cfg)
+    cfg = re.sub(r'MAXL = \d+', 'MAXL = %d' % maxl, cfg)
+    cfg = cfg.replace('REGULARIZATION_LIST = 0thorder', 'REGULARIZATION_LIST = ' + reg)
+    it = make_interp(tmp_path, cfg)
+    assert it.regularization_list == [reg] and it.model.nbasis == maxk * maxl**2
+    lat, lon, alt = synth.beams(*synth.GEOM_C1, seed=seed)
+    o = oracle.SphHarmLagOracle(maxk=maxk, maxl=maxl)
+    A = o.basis(lat, lon, alt)
+    T = 8
+    value, error = synth.synth_records(A, T, seed0=seed * 10)
+    value[2, 5:9] = np.nan                                       # dropped points (interpolate.py:516-520)
+    R = it.model.eval_reg_matricies[reg]()
+    res = it.fit_records(lat, lon, alt, value, error, {reg: R})
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        C, dC, c2, params = oracle.fit_records(o, lat, lon, alt, value, error, {reg: R}, [reg])
+        Cp, _, _, _ = oracle.fit_records(_PerturbedBasis(o, seed), lat, lon, alt, value, error, {reg: R}, [reg])
+    checked = 0
+    for t in range(T):
+        a_ref, a = params[t][reg], res['reg_params'][t][reg]
+        if np.isnan(a_ref):
+            assert np.isnan(a) and np.all(np.isnan(res['Coeffs'][t])), t
+            continue
+        sn = rel(Cp[t], C[t]) if np.all(np.isfinite(Cp[t])) else float('inf')
+        if not sn < 1e-5:
+            print('[order (%d,%d) %s record %d] not screened: oracle self-noise %.1e; GPU vs oracle rel(C) %.1e' %
+                  (maxk, maxl, reg, t, sn, rel(res['Coeffs'][t], C[t])))
+            continue
+        checked += 1
+        tol = max(1e-6, 10 * sn)
+        if a_ref == 0:
+            assert a == 0
+        else:
+            assert abs(math.log10(a) - math.log10(a_ref)) <= max(1e-7, tol), t
+        assert rel(res['Coeffs'][t], C[t]) <= tol, (t, sn)
+        assert abs(res['chi_sq'][t] - c2[t]) <= max(1e-6, tol) * c2[t]
+    if checked < 2:
+        pytest.skip('the oracle does not reproduce itself at this order (fewer than 2 of %d records pass the screen)' % T)
 
 
 def test_fit_edge_outcomes(tmp_path):
