@@ -273,6 +273,8 @@ struct EvalSink {
 // reused by every timestep tile of the evaluation.
 constexpr float HULL_BAND = 4.0f;
 
+constexpr int HULL_PP = 4;          // points per thread: every facet read from LDS serves four points
+
 __global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __restrict__ lat,
                                                      const double* __restrict__ lon, const double* __restrict__ alt,
                                                      const double* __restrict__ hull, int F, double tol,
@@ -282,39 +284,67 @@ __global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __
     const float4* __restrict__ pl = reinterpret_cast<const float4*>(hull + 4 + 4 * (size_t)F);
     for (int f = threadIdx.x; f < F; f += BLOCK) shpl[f] = pl[f];
     __syncthreads();
-    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int64_t qc = q < Q ? q : Q - 1;
-    double X, Y, Z;
-    geodetic2ecef(lat[qc], lon[qc], alt[qc], X, Y, Z);
-    const float dx = (float)(X - hull[0]), dy = (float)(Y - hull[1]), dz = (float)(Z - hull[2]);
-    float dmax = -3.0e38f;
+    const int64_t q0 = (int64_t)blockIdx.x * (BLOCK * HULL_PP) + threadIdx.x;      // points q0 + u * BLOCK
+    double X[HULL_PP], Y[HULL_PP], Z[HULL_PP];
+    float dx[HULL_PP], dy[HULL_PP], dz[HULL_PP], dmax[HULL_PP];
+#pragma unroll
+    for (int u = 0; u < HULL_PP; ++u) {
+        const int64_t q = q0 + (int64_t)u * BLOCK;
+        const int64_t qc = q < Q ? q : Q - 1;
+        geodetic2ecef(lat[qc], lon[qc], alt[qc], X[u], Y[u], Z[u]);
+        dx[u] = (float)(X[u] - hull[0]);
+        dy[u] = (float)(Y[u] - hull[1]);
+        dz[u] = (float)(Z[u] - hull[2]);
+        dmax[u] = -3.0e38f;
+    }
+    const float out_thr = (float)tol + HULL_BAND;
+    // two points per packed fp32 FMA (v_pk_fma_f32): the pass is VALU-bound (~2/3 of the scalar fp32 issue rate before)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 px[HULL_PP / 2], py[HULL_PP / 2], pz[HULL_PP / 2];
+#pragma unroll
+    for (int h = 0; h < HULL_PP / 2; ++h) {
+        px[h] = f2{dx[2 * h], dx[2 * h + 1]};
+        py[h] = f2{dy[2 * h], dy[2 * h + 1]};
+        pz[h] = f2{dz[2 * h], dz[2 * h + 1]};
+    }
+    auto facet = [&](const float4 p) {
+#pragma unroll
+        for (int h = 0; h < HULL_PP / 2; ++h) {
+            const f2 d = __builtin_elementwise_fma(f2{p.x, p.x}, px[h],
+                                                   __builtin_elementwise_fma(f2{p.y, p.y}, py[h],
+                                                                             __builtin_elementwise_fma(f2{p.z, p.z}, pz[h], f2{p.w, p.w})));
+            dmax[2 * h] = fmaxf(dmax[2 * h], d.x);
+            dmax[2 * h + 1] = fmaxf(dmax[2 * h + 1], d.y);
+        }
+    };
     int f = 0;
     for (; f + 8 <= F; f += 8) {
-        float d[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 p = shpl[f + u];
-            d[u] = fmaf(p.x, dx, fmaf(p.y, dy, fmaf(p.z, dz, p.w)));
-        }
+        for (int v = 0; v < 8; ++v) facet(shpl[f + v]);
+        // a point is outside as soon as ONE facet says so: leave when every point of the wave is decided
+        bool done = true;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dmax = fmaxf(dmax, d[u]);
+        for (int u = 0; u < HULL_PP; ++u) done = done && dmax[u] > out_thr;
+        if (__all(done)) break;
     }
-    for (; f < F; ++f) {
-        const float4 p = shpl[f];
-        dmax = fmaxf(dmax, fmaf(p.x, dx, fmaf(p.y, dy, fmaf(p.z, dz, p.w))));
-    }
-    bool in;
-    if (dmax > (float)tol + HULL_BAND) in = false;
-    else if (dmax < (float)tol - HULL_BAND) in = true;
-    else {                                                               // borderline: exact fp64 test
-        const double* __restrict__ eq = hull + 4;
-        in = true;
-        for (int g = 0; g < F; ++g) {
-            const double d = fma(eq[4 * g], X, fma(eq[4 * g + 1], Y, fma(eq[4 * g + 2], Z, eq[4 * g + 3])));
-            in = in && (d <= tol);
+    if (f + 8 > F)
+        for (; f < F; ++f) facet(shpl[f]);
+#pragma unroll
+    for (int u = 0; u < HULL_PP; ++u) {
+        bool in;
+        if (dmax[u] > out_thr) in = false;
+        else if (dmax[u] < (float)tol - HULL_BAND) in = true;
+        else {                                                           // borderline: exact fp64 test
+            const double* __restrict__ eq = hull + 4;
+            in = true;
+            for (int g = 0; g < F; ++g) {
+                const double d = fma(eq[4 * g], X[u], fma(eq[4 * g + 1], Y[u], fma(eq[4 * g + 2], Z[u], eq[4 * g + 3])));
+                in = in && (d <= tol);
+            }
         }
+        const int64_t q = q0 + (int64_t)u * BLOCK;
+        if (q < Q) mask[q] = in ? 1 : 0;
     }
-    if (q < Q) mask[q] = in ? 1 : 0;
 }
 
 // hullbuf <- [c0][eq][float4 facets]; c0 = foot of the origin's perpendicular on facet 0 (a point of the hull surface)
@@ -813,7 +843,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
             VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
             m->mask_bytes = (size_t)Q;
         }
-        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
+        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
                            d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
         VI_HIP(hipGetLastError());
     }
