@@ -73,6 +73,76 @@ __device__ __forceinline__ int slot_next(int s, int m)
 // original index held by slot s in the initial arrangement: top row 0..m-1, bottom row m..2m-1
 __device__ __forceinline__ int slot_orig0(int s, int m) { return (s & 1) ? m + (s >> 1) : (s >> 1); }
 
+// ---- reverse replay of the rotation log on ONE vector held in the registers of one wave ------------------------
+// g <- J g per round, where round r first rotated every pair and then applied the slot permutation pi
+// (slot_next).  In the reverse direction pair P = (slots 2P, 2P+1) therefore gathers from pi(2P), pi(2P+1): the
+// TOP element of the next pair and the BOTTOM element of the previous one (the music-chairs ring), with two
+// exceptions: pair 0 takes (top[0], top[1]) and the last pair takes (its own bottom, bot[m-2]).  Lane l holds pairs
+// l and l + 64 (m <= 128), so both gathers are single-lane shifts of the wave: DPP wave_shl:1 / wave_shr:1 (8 cycles)
+// instead of an LDS write + read per round (the LDS version spent ~350 cycles per round on that round trip, 19 %
+// of the whole solve; tools/exp_stamps.py).  Arithmetic and its order are those of the LDS version.
+struct WaveReplay {
+    int lane, last0, last1;
+    bool has0, has1;
+    double t0, b0, t1, b1;
+
+    __device__ __forceinline__ static double from_next(double v, double edge)    // lane i <- v[i + 1]; lane 63 <- edge
+    {
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ static double from_prev(double v, double edge)    // lane i <- v[i - 1]; lane 0 <- edge
+    {
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ static double lane_value(double v, int l)          // wave-uniform copy of v[l]
+    {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                                __builtin_amdgcn_readlane(__double2loint(v), l));
+    }
+    __device__ __forceinline__ void init(int lane_, int m)
+    {
+        lane = lane_;
+        has0 = lane < m;
+        has1 = lane + 64 < m;
+        last0 = m <= 64 ? m - 1 : -1;
+        last1 = m > 64 ? m - 1 - 64 : -1;
+    }
+    __device__ __forceinline__ void load(const double* y)
+    {
+        t0 = has0 ? y[2 * lane] : 0.0;
+        b0 = has0 ? y[2 * lane + 1] : 0.0;
+        t1 = has1 ? y[2 * (lane + 64)] : 0.0;
+        b1 = has1 ? y[2 * (lane + 64) + 1] : 0.0;
+    }
+    __device__ __forceinline__ void store(double* y) const
+    {
+        if (has0) { y[2 * lane] = t0; y[2 * lane + 1] = b0; }
+        if (has1) { y[2 * (lane + 64)] = t1; y[2 * (lane + 64) + 1] = b1; }
+    }
+    // r0 / r1: (c, s) of pairs lane / lane + 64 in this round ((1, 0) where there is no pair)
+    __device__ __forceinline__ void round(double2 r0, double2 r1)
+    {
+        const double top64 = lane_value(t1, 0);          // top[64]  -> gather of pair 63
+        const double bot63 = lane_value(b0, 63);         // bot[63]  -> gather of pair 64
+        const double nx0 = from_next(t0, top64);         // top[l + 1]
+        const double nx1 = from_next(t1, 0.0);           // top[l + 65]
+        const double pv0 = from_prev(b0, 0.0);           // bot[l - 1]
+        const double pv1 = from_prev(b1, bot63);         // bot[l + 63]
+        const double gp0 = lane == 0 ? t0 : (lane == last0 ? b0 : nx0);
+        const double gq0 = lane == 0 ? nx0 : pv0;
+        const double gp1 = lane == last1 ? b1 : nx1;
+        const double gq1 = pv1;
+        t0 = r0.x * gp0 + r0.y * gq0;
+        b0 = -r0.y * gp0 + r0.x * gq0;
+        t1 = r1.x * gp1 + r1.y * gq1;
+        b1 = -r1.y * gp1 + r1.x * gq1;
+    }
+};
+
 template <int IT>
 __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __restrict__ X,
                                                       const double* __restrict__ scl, const double* __restrict__ y,
@@ -232,7 +302,6 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
     }
     // ---- truncated solve in the eigenbasis (slot order) ---------------------------------------------
     double* yc = yv + ycur * Np;
-    double* yo = yv + (ycur ^ 1) * Np;
     double mx = 0.0;
     for (int i = tid; i < Np; i += JBS) mx = fmax(mx, fabs(A[tri(i, i)]));
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -266,51 +335,34 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         if (nround_out) nround_out[sys] = (int)nround;
     }
     VI_STAMP(5);
-    // ---- C = V g : undo (permutation, rotation) round by round, one barrier per round --------------------
-    // Done by wave 0 alone: the DS operations of one wave execute in order, so the write -> read hand-over between
-    // consecutive rounds needs no workgroup barrier (which cost ~1.1k cycles per round with 8 waves, 31 % of the
-    // kernel).  Lane l owns pairs l and l + 64.
+    // ---- C = V g : undo (permutation, rotation) round by round ----------------------------------------------
+    // Done by wave 0 alone with the vector in its registers (WaveReplay): a workgroup barrier per round cost ~1.1k
+    // cycles with 8 waves (31 % of the kernel), a single wave going through LDS ~350 cycles (19 %).
     if (tid < 64) {
         constexpr int PF = 8;                           // rounds of (c, s) prefetched per batch
         const int P1 = tid + 64;
-        const bool has1 = P1 < m, has0 = tid < m;
-        const int q0 = 2 * P1, q1 = 2 * P1 + 1;
-        const int m0 = slot_next(has1 ? q0 : 0, m), m1 = slot_next(has1 ? q1 : 1, m);
+        WaveReplay W;
+        W.init(tid, m);
+        W.load(yc);
         for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
             const int nb = r1 >= PF ? PF : (int)r1;
             double2 pf0[PF], pf1[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                pf0[u] = make_double2(1.0, 0.0);
+                pf1[u] = make_double2(1.0, 0.0);
                 if (u < nb) {
-                    if (has0) pf0[u] = logp[(r1 - 1 - u) * m + tid];
-                    if (has1) pf1[u] = logp[(r1 - 1 - u) * m + P1];
+                    if (W.has0) pf0[u] = logp[(r1 - 1 - u) * m + tid];
+                    if (W.has1) pf1[u] = logp[(r1 - 1 - u) * m + P1];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (u < nb) {
-                    if (has0) {
-                        const double gp = yc[n0], gq = yc[n1];       // values that slots p0, p1 were moved to
-                        yo[p0] = pf0[u].x * gp + pf0[u].y * gq;      // g <- J g
-                        yo[p1] = -pf0[u].y * gp + pf0[u].x * gq;
-                    }
-                    if (has1) {
-                        const double gp = yc[m0], gq = yc[m1];
-                        yo[q0] = pf1[u].x * gp + pf1[u].y * gq;
-                        yo[q1] = -pf1[u].y * gp + pf1[u].x * gq;
-                    }
-                    double* t = yc; yc = yo; yo = t;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
+            for (int u = 0; u < PF; ++u)
+                if (u < nb) W.round(pf0[u], pf1[u]);
         }
-        if (yc != yv + ycur * Np) ycur ^= 1;          // which buffer holds the result
+        W.store(yc);                                    // back into the buffer it came from
     }
-    // broadcast the parity of the final buffer from wave 0 (nd[0] is free now)
-    if (tid == 0) nd[0] = (double)ycur;
     __syncthreads();
-    yc = yv + ((int)nd[0]) * Np;
     VI_STAMP(6);
     for (int s = tid; s < Np; s += JBS) {
         const int o = slot_orig0(s, m);
@@ -386,77 +438,49 @@ __global__ __launch_bounds__(JBS) void k_jacobi_vectors(int N, const double2* __
     }
 }
 
-// Latency variant for FEW systems (a single record's prepare / final solve): one WAVE per strip of CPW columns, no
-// workgroup barrier at all - the DS operations of one wave execute in order, so the write -> read hand-over between
-// consecutive rounds needs only a wave fence (the same replay wave 0 of k_jacobi_solve runs for C = V g).  Lane l
-// owns pairs l and l + 64; the (c, s) of a round are loaded once and applied to the CPW columns of the strip.
-// N / CPW independent waves per system spread over as many CUs.  Even N <= 256 only.
-template <int CPW>
+// Latency variant for FEW systems (a single record's prepare / final solve): one WAVE per column, the column in the
+// wave's registers (WaveReplay) - no LDS, no barrier.  N independent single-wave workgroups per system spread over as
+// many CUs.  Even N <= 256 only.
 __global__ __launch_bounds__(64) void k_jacobi_vectors_wave(int N, const double2* __restrict__ rotlog, int64_t log_stride,
                                                             const int* __restrict__ nround_in, double* __restrict__ Vout)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int m = N >> 1;
-    double* buf0 = reinterpret_cast<double*>(lds_raw);               // [N][CPW]
-    double* buf1 = buf0 + (size_t)N * CPW;
     const int lane = threadIdx.x;
     const int64_t sys = blockIdx.x;
-    const int c0 = blockIdx.y * CPW;
+    const int col = blockIdx.y;                         // final slot whose eigenvector this wave builds
     const double2* logp = rotlog + sys * log_stride;
     const int64_t nround = nround_in[sys];
-    for (int i = lane; i < N * CPW; i += 64) {
-        const int s = i / CPW, c = i - s * CPW;
-        buf0[i] = (s == c0 + c) ? 1.0 : 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    WaveReplay W;
+    W.init(lane, m);
+    W.t0 = (2 * lane == col) ? 1.0 : 0.0;
+    W.b0 = (2 * lane + 1 == col) ? 1.0 : 0.0;
+    W.t1 = (2 * (lane + 64) == col) ? 1.0 : 0.0;
+    W.b1 = (2 * (lane + 64) + 1 == col) ? 1.0 : 0.0;
     constexpr int PF = 8;                               // rounds of (c, s) prefetched per batch
-    const int P0 = lane, P1 = lane + 64;
-    const bool has0 = P0 < m, has1 = P1 < m;
-    const int p0 = 2 * P0, p1 = 2 * P0 + 1, q0 = 2 * P1, q1 = 2 * P1 + 1;
-    const int n0 = slot_next(has0 ? p0 : 0, m) * CPW, n1 = slot_next(has0 ? p1 : 1, m) * CPW;
-    const int m0 = slot_next(has1 ? q0 : 0, m) * CPW, m1 = slot_next(has1 ? q1 : 1, m) * CPW;
-    double* yc = buf0;
-    double* yo = buf1;
     for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
         const int nb = r1 >= PF ? PF : (int)r1;
         double2 pf0[PF], pf1[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
+            pf0[u] = make_double2(1.0, 0.0);
+            pf1[u] = make_double2(1.0, 0.0);
             if (u < nb) {
-                if (has0) pf0[u] = logp[(r1 - 1 - u) * m + P0];
-                if (has1) pf1[u] = logp[(r1 - 1 - u) * m + P1];
+                if (W.has0) pf0[u] = logp[(r1 - 1 - u) * m + lane];
+                if (W.has1) pf1[u] = logp[(r1 - 1 - u) * m + lane + 64];
             }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (u < nb) {
-                if (has0) {
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c) {
-                        const double gp = yc[n0 + c], gq = yc[n1 + c];
-                        yo[p0 * CPW + c] = pf0[u].x * gp + pf0[u].y * gq;
-                        yo[p1 * CPW + c] = -pf0[u].y * gp + pf0[u].x * gq;
-                    }
-                }
-                if (has1) {
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c) {
-                        const double gp = yc[m0 + c], gq = yc[m1 + c];
-                        yo[q0 * CPW + c] = pf1[u].x * gp + pf1[u].y * gq;
-                        yo[q1 * CPW + c] = -pf1[u].y * gp + pf1[u].x * gq;
-                    }
-                }
-                double* t = yc; yc = yo; yo = t;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+        for (int u = 0; u < PF; ++u)
+            if (u < nb) W.round(pf0[u], pf1[u]);
     }
-    double* Vo = Vout + sys * (int64_t)N * N;
-    for (int i = lane; i < N * CPW; i += 64) {
-        const int c = i / N, s = i - c * N;                          // s fastest: contiguous stores
-        if (c0 + c < N) Vo[(int64_t)(c0 + c) * N + slot_orig0(s, m)] = yc[s * CPW + c];
+    double* Vo = Vout + sys * (int64_t)N * N + (int64_t)col * N;     // eigenvector `col`, indexed by original index
+    if (W.has0) {
+        Vo[slot_orig0(2 * lane, m)] = W.t0;
+        Vo[slot_orig0(2 * lane + 1, m)] = W.b0;
+    }
+    if (W.has1) {
+        Vo[slot_orig0(2 * (lane + 64), m)] = W.t1;
+        Vo[slot_orig0(2 * (lane + 64) + 1, m)] = W.b1;
     }
 }
 
@@ -574,8 +598,9 @@ static int launch_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int ma
 
 int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
 {
-    // very few systems (one record's prepare / final solve): one barrier-free wave per column (measured at N = 144,
-    // one system: 0.62 ms for 1 column per wave, 0.94 for 2, 1.8 for 4; the workgroup kernel below takes 1.47 ms);
+    // very few systems (one record's prepare / final solve): one wave per column with the column in registers
+    // (measured at N = 144, one system: 1.47 ms for the workgroup kernel below, 0.62 ms for one column per wave through
+    // LDS, and the register version after that);
     // few systems: narrow column blocks spread one system over more CUs (latency); many systems: wide blocks
     // re-read the rotation log fewer times (throughput)
     static int wave_ok = -1;
@@ -583,25 +608,11 @@ int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sw
         const char* e = getenv("VINTERP_VECTORS");
         wave_ok = (e && !strcmp(e, "block")) ? 0 : 1;
     }
-    static int cpw = -1;
-    if (cpw < 0) {
-        const char* e = getenv("VINTERP_VECTORS_CPW");
-        cpw = e ? atoi(e) : 1;
-    }
-    if (wave_ok && N <= 256 && (N % 2) == 0 && B * ((N + cpw - 1) / cpw) <= 2 * c->n_cu) {
+    if (wave_ok && N <= 256 && (N % 2) == 0 && B * N <= 2 * c->n_cu) {
         const int m = N / 2;
         const int64_t log_stride = (int64_t)max_sweeps * (N - 1) * m;
-        const size_t shm = (size_t)2 * N * cpw * sizeof(double);
-        const dim3 grid((unsigned)B, (unsigned)((N + cpw - 1) / cpw));
-        if (cpw == 1)
-            hipLaunchKernelGGL(k_jacobi_vectors_wave<1>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
-                               d_nround, d_V);
-        else if (cpw == 2)
-            hipLaunchKernelGGL(k_jacobi_vectors_wave<2>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
-                               d_nround, d_V);
-        else
-            hipLaunchKernelGGL(k_jacobi_vectors_wave<4>, grid, dim3(64), shm, c->stream, N, (const double2*)d_log, log_stride,
-                               d_nround, d_V);
+        hipLaunchKernelGGL(k_jacobi_vectors_wave, dim3((unsigned)B, (unsigned)N), dim3(64), 0, c->stream, N,
+                           (const double2*)d_log, log_stride, d_nround, d_V);
         VI_HIP(hipGetLastError());
         return VI_OK;
     }
