@@ -181,6 +181,14 @@ int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, co
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
                        double rcond, double* d_C, int32_t* d_rank);
 
+/* One root-finder iterate of ONE record in a single call (single-record latency path): vi_warm_solve_f64 for
+ * (slot, alpha) followed by vi_chi2_f64 against record `rec`; the scalars travel as kernel arguments and the only
+ * synchronisation is the read-back of chi^2 into *h_chi2 (host).  d_scratch: N + 8 doubles of device memory. */
+int  vi_warm_chi2_one_f64(vi_ctx* ctx, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
+                          const double* d_yt, const double* d_V, int32_t slot, double alpha, double rcond,
+                          const double* d_At, int32_t rec, const double* d_W, const double* d_b,
+                          double* d_scratch, double* h_chi2);
+
 /* ---- generalised cross validation: replaces the loop of Interpolate.gcvobjfunct (interpolate.py:332-351) ----
  * For ONE record (d_AWA N x N, d_y N, d_W / d_b P) and one alpha: res[i] = W_p (a_p . C_(-p) - b_p)^2 for the np
  * data points p = pidx[i], where C_(-p) is the regularised truncated solution of the fit that leaves point p

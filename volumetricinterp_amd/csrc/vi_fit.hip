@@ -619,6 +619,43 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
     return VI_OK;
 }
 
+// One root-finder iterate of ONE record in a single call (the latency path of a single-record fit: ~14 dependent
+// iterates per record): the scalars travel as kernel arguments instead of three host-to-device copies, and the only
+// synchronisation is the 8-byte read-back of chi^2.  d_scratch: N + 8 doubles owned by the caller.
+namespace {
+__global__ void k_set_one(double* scratch, double alpha, int slot, int rec)
+{
+    scratch[0] = alpha;
+    int* iv = reinterpret_cast<int*>(scratch + 2);
+    iv[0] = slot;
+    iv[1] = rec;
+}
+}  // namespace
+
+extern "C" int vi_warm_chi2_one_f64(vi_ctx* c, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
+                                    const double* d_yt, const double* d_V, int32_t slot, double alpha, double rcond,
+                                    const double* d_At, int32_t rec, const double* d_W, const double* d_b,
+                                    double* d_scratch, double* h_chi2)
+{
+    VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_At && d_W && d_b && d_scratch && h_chi2, "null argument");
+    VI_REQUIRE(N > 0 && P > 0 && slot >= 0 && rec >= 0, "bad size");
+    VI_HIP(hipSetDevice(c->device));
+    double* d_alpha = d_scratch;
+    double* d_chi = d_scratch + 1;
+    int32_t* d_slot = reinterpret_cast<int32_t*>(d_scratch + 2);
+    int32_t* d_rec = d_slot + 1;
+    double* d_C = d_scratch + 8;
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, c->stream, d_scratch, alpha, (int)slot, (int)rec);
+    VI_HIP(hipGetLastError());
+    int rc = vi_warm_solve_f64(c, 1, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, nullptr);
+    if (rc != VI_OK) return rc;
+    rc = vi_chi2_f64(c, 1, P, N, d_At, d_C, d_rec, d_W, d_b, d_chi);
+    if (rc != VI_OK) return rc;
+    VI_HIP(hipMemcpyAsync(h_chi2, d_chi, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VI_HIP(hipStreamSynchronize(c->stream));
+    return VI_OK;
+}
+
 // ---- generalised cross validation objective (interpolate.py:299-351) -----------------------------------
 // For one record (normal equations d_AWA (N x N), d_y (N), weights / data d_W, d_b (P)) and one alpha: the sum
 // over the np listed data points of the squared, weighted residual of each point against the fit that leaves it

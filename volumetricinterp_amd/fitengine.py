@@ -36,10 +36,13 @@ _lib._sig('vi_warm_prepare_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib
           _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_warm_chi2_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          C.c_int32, C.c_double, C.c_double, _lib.VOIDP, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          C.POINTER(C.c_double))
 _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, C.c_double, _lib.VOIDP)
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -220,6 +223,23 @@ class FitEngine(object):
             import time
             t_tr = time.perf_counter()
         is_int = log10a == np.floor(log10a)
+        if B == 1 and not is_int[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot:
+            # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
+            dV, dD1, dD2, dyt = self._warm_buffers('w_')
+            scratch = self._buf('w_one', (N + 8,))
+            chi = C.c_double(0.)
+            r = int(rec[0])
+            _lib.check(_lib.lib.vi_warm_chi2_one_f64(self.ctx.handle, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr,
+                                                     self._warm_slot[r], float(np.power(10., log10a[0])), EPS,
+                                                     self.At.ptr, r, self.dW.ptr, self.db.ptr, scratch.ptr,
+                                                     C.byref(chi)), 'vi_warm_chi2_one_f64')
+            self.stats['solves'] += 1
+            self.stats['launches'] += 1
+            self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + 1
+            if trace:
+                print('[search round] B=1 warm (single call)  %.2f ms  log10a[0]=%.12f' %
+                      ((time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            return np.array([chi.value])
         if not self.warm_enabled():
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
