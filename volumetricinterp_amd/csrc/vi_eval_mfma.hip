@@ -125,7 +125,7 @@ struct MainSeg {
 constexpr int MBLOCK = 256;      // 4 waves x 64 points
 
 template <int L, int KQ, int NT>
-__global__ __launch_bounds__(MBLOCK) void k_eval_sph_mfma(SphDev M, int64_t Q, const double* __restrict__ lat,
+__global__ __launch_bounds__(MBLOCK, (NT >= 2 ? 2 : 1)) void k_eval_sph_mfma(SphDev M, int64_t Q, const double* __restrict__ lat,
                                                           const double* __restrict__ lon, const double* __restrict__ alt,
                                                           int tcount, const double* __restrict__ Cp,
                                                           const unsigned char* __restrict__ mask, int F, int ngrp,
