@@ -195,10 +195,10 @@ def test_eval_matrix_core_tiles_vs_oracle(tag, maxk, maxl):
 
 @pytest.mark.parametrize('maxk,maxl,cap', [(4, 3, 10.), (2, 12, 15.), (4, 6, 12.7)])
 def test_eval_matrix_core_other_orders_vs_oracle(maxk, maxl, cap):
-    """The other instantiations of the matrix-core kernel: MAXL 3 x MAXK 4 (integer degrees); MAXL 12 x MAXK 2 (a
-    Laguerre quad padded with zero coefficients; CAP_LIM 15: half-integer degrees, 2F1 seeds; at CAP_LIM 10 this order
-    overflows Kvm, F8, and every density is NaN as in the reference); and an order the kernel declines (CAP_LIM 12.7:
-    several degree groups), which must fall through to the generic kernel."""
+    """Other orders through the multi-timestep dispatch: MAXL 3 x MAXK 4 (matrix-core kernel, integer degrees); MAXL 12 x
+    MAXK 2 at CAP_LIM 15 (half-integer degrees, 2F1 seeds; no matrix-core instantiation: VALU tiles; at CAP_LIM 10 this
+    order overflows Kvm, F8, and every density is NaN as in the reference); and CAP_LIM 12.7 (several degree groups: the
+    generic kernel)."""
     import oracle
     from volumetricinterp_amd.estimate import Estimate
     from volumetricinterp_amd import synth

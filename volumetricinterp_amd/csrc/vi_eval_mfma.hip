@@ -358,7 +358,8 @@ int vi_eval_sph_mfma(vi_model* m, int64_t Q, const double* lat, const double* lo
     VI_MFMA(6, 4);
     VI_MFMA(3, 4);
     VI_MFMA(2, 8);
-    VI_MFMA(12, 2);
+    // MAXL = 12: the 144-row coefficient image exceeds the LDS share of a workgroup, and with a 96 KB image the kernel
+    // measured no faster than the VALU tile kernel (5.48 vs 5.50 ms for 32 timesteps x 128^3 at MAXK = 2): not built
 #undef VI_MFMA
     return VI_OK;
 }
