@@ -287,7 +287,7 @@ def test_default_order_report(tmp_path, capsys):
 
 def test_solver_fallback_outside_the_in_lds_range():
     """N = 200 does not fit the in-LDS Jacobi kernel (161 KB > 160 KB LDS): vi_solve_trunc_f64 falls back to
-    rocSOLVER syevj on the rescaled system - same truncation semantics, with and without pinv."""
+    rocSOLVER syevd on the rescaled system - same truncation semantics, with and without pinv."""
     rng = np.random.default_rng(3)
     B, N = 3, 200
     X, Y = [], []
