@@ -173,6 +173,48 @@ __global__ __launch_bounds__(BS) void k_scale_system(int NN, double* __restrict_
     if (tid == 0) scl[i] = 1.0 / f;      // exact (power of two)
 }
 
+// k_form_pair followed by k_scale_system in one pass: X[i] = f * (D1[slot] + alpha D2[slot]), scl[i] = 1 / f with f the
+// power of two that brings max|X| into [1, 2).  The elements stay in registers between the max reduction and the
+// store (NN <= EPT * BS), so D1 and D2 are read once and X is written once (a single-record root-finder iterate spent
+// 45 us in the two separate kernels against ~1 ms in the solve).
+template <int BS, int EPT>
+__global__ __launch_bounds__(BS) void k_form_pair_scaled(int NN, const double* __restrict__ D1, const double* __restrict__ D2,
+                                                         const int* __restrict__ slot, const double* __restrict__ alpha,
+                                                         double* __restrict__ X, double* __restrict__ scl)
+{
+    __shared__ double red[BS / 64];
+    const int64_t i = blockIdx.x;
+    const int64_t w = slot[i];
+    const double a = alpha[i];
+    const int tid = threadIdx.x;
+    double v[EPT];
+    double mx = 0.0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = tid + u * BS;
+        v[u] = e < NN ? fma(a, D2[w * NN + e], D1[w * NN + e]) : 0.0;
+        mx = fmax(mx, fabs(v[u]));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < BS / 64; ++q) mx = fmax(mx, red[q]);
+    int ex = 0;
+    double f = 1.0;
+    if (mx > 0.0 && mx < 1.7e308) {
+        (void)frexp(mx, &ex);            // mx = m * 2^ex, m in [0.5, 1)
+        f = ldexp(1.0, 1 - ex);          // mx * f in [1, 2)
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = tid + u * BS;
+        if (e < NN) X[i * NN + e] = v[u] * f;
+    }
+    if (tid == 0) scl[i] = 1.0 / f;      // exact (power of two)
+}
+
 // One workgroup per system: given eigenpairs (V column-major, lam) form the truncated minimum-norm
 // solution C = V diag(1/lam | |lam| > rcond*max|lam|) V^T y   (gelsd semantics for symmetric X)
 // and optionally the scaled eigenvectors Vs = V diag(w_pinv) for H = Vs V^T.
@@ -605,9 +647,14 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
     double* cp = X + (size_t)Bc * NN;
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
-        hipLaunchKernelGGL(k_form_pair, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_D1, d_D2, d_slot + i0,
-                           d_alpha + i0, X);
-        hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, X, scl);
+        if (NN <= 24 * 1024) {
+            hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, d_D1, d_D2,
+                               d_slot + i0, d_alpha + i0, X, scl);
+        } else {
+            hipLaunchKernelGGL(k_form_pair, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_D1, d_D2, d_slot + i0,
+                               d_alpha + i0, X);
+            hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, X, scl);
+        }
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, d_slot + i0, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
                              JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
