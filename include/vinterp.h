@@ -113,6 +113,11 @@ int  vi_basis_f64(vi_model* model, int64_t P, const double* d_lat, const double*
  * G[p*ld_p + c*ld_c + n*ld_n], c = 0,1,2 = components along z, theta, phi.  sphharmlag only. */
 int  vi_grad_basis_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
                        const double* d_alt, double* d_G, int64_t ld_p, int64_t ld_c, int64_t ld_n);
+/* gradient of the fitted parameter, out[q*3 + c] = sum_n grad_basis[q][c][n] * C[n] (c = z, theta, phi components as
+ * sphharmlag.py:148-184 defines them): the contraction the reference's Estimate.__call__ advertises as `calcgrad`
+ * (estimate.py:125-147, dead code there); the (Q, 3, N) array is never formed. */
+int  vi_eval_grad_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                      const double* d_C, double* d_out);
 /* model coordinates (z, theta, phi) of sphharmlag.py:324-359 `transform_coord`; ECEF x,y,z for RBF */
 int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
                       const double* d_alt, double* d_c0, double* d_c1, double* d_c2);

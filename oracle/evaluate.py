@@ -51,3 +51,15 @@ def evaluate(model, C, gdlat, gdlon, gdalt, hull_vert=None):
     if hull_vert is not None:
         parameter[~check_hull(hull_vert, gdlat, gdlon, gdalt)] = np.nan
     return parameter
+
+
+def evaluate_gradient(model, C, gdlat, gdlon, gdalt, hull_vert=None):
+    """Gradient of the fitted parameter: grad_basis (sphharmlag.py:148-184) contracted with C - what the dead code after
+    the return of Estimate.__call__ (estimate.py:125-147) was meant to deliver.  Shape gdlat.shape + (3,)."""
+    gdlat = np.asarray(gdlat, dtype=np.float64)
+    G = model.grad_basis(gdlat.ravel(), np.asarray(gdlon, dtype=np.float64).ravel(),
+                         np.asarray(gdalt, dtype=np.float64).ravel())                  # (P, 3, N)
+    out = np.einsum('pcn,n->pc', G, np.asarray(C, dtype=np.float64))
+    if hull_vert is not None:
+        out[~check_hull(hull_vert, gdlat.ravel(), np.asarray(gdlon).ravel(), np.asarray(gdalt).ravel())] = np.nan
+    return out.reshape(gdlat.shape + (3,))

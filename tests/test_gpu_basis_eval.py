@@ -248,3 +248,32 @@ def test_grad_basis_vs_reference(tag):
         err = colnorm_err(G[:, c, :], Gref[:, c, :])
         assert np.max(err) <= 1e-11, (tag, c, float(np.max(err)), int(np.argmax(err)))
     assert m.grad_basis(np.zeros(0), np.zeros(0), np.zeros(0)).shape == (0, 3, m.nbasis)
+
+
+@pytest.mark.parametrize('tag', ['k8l2', 'default'])
+def test_estimate_gradient_vs_oracle(tag):
+    """Estimate.gradient (fused device contraction of grad_basis with the coefficients, vi_eval_grad_f64) against the
+    oracle's grad_basis @ C, with the hull mask of the value path, on an N-D grid."""
+    import oracle
+    from volumetricinterp_amd import synth
+    f, es = _estimate(tag)
+    maxk, maxl = (8, 2) if tag == 'k8l2' else (4, 6)
+    o = oracle.SphHarmLagOracle(maxk=maxk, maxl=maxl)
+    grid = synth.query_grid(5)
+    t_mid = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(np.mean(f['utime'][0])))
+    C, _ = oracle.get_C(t_mid, f['utime'], np.nan_to_num(f['Coeffs']), f['Covariance'])
+    es.Coeffs = np.nan_to_num(es.Coeffs)
+    g = es.gradient(t_mid, *grid, check_hull=False)
+    assert g.shape == (5, 5, 5, 3)
+    ref = oracle.evaluate_gradient(o, C, *grid)
+    for c in range(3):
+        assert rel(g[..., c], ref[..., c]) <= 1e-10, c
+    gh = es.gradient(t_mid, *grid)                                       # hull mask on by default, like __call__
+    refh = oracle.evaluate_gradient(o, C, *grid, hull_vert=f['hull_vert'])
+    assert np.array_equal(np.isnan(gh), np.isnan(refh))
+    ok = np.isfinite(refh)
+    assert ok.any() and rel(gh[ok], refh[ok]) <= 1e-10
+    # consistency with the materialised gradient basis
+    G = es.model.grad_basis(grid[0].ravel(), grid[1].ravel(), grid[2].ravel())
+    assert rel(g.reshape(-1, 3), np.einsum('pcn,n->pc', G, C)) <= 1e-12
+    assert es.gradient(t_mid, grid[0][:0, 0, 0], grid[1][:0, 0, 0], grid[2][:0, 0, 0]).shape == (0, 3)

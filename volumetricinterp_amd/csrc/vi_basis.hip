@@ -128,11 +128,16 @@ __global__ __launch_bounds__(BLOCK) void k_basis_sph(SphDev M, int64_t P, const 
 //   phat = e L0 Pmv dAz / (y (z/100+1) RE),
 // with L1 = eval_genlaguerre(k-1, 1, z), Pmv1 = lpmv(m, v+1, x).  Same chains as the basis, run one degree
 // further: when the chain has reached degree nu_l + 1, prev holds P at nu_l and cur at nu_l + 1.
-template <int LCAP, int KCAP>
+// CONTRACT = false: store the (P, 3, N) gradient basis.  CONTRACT = true: contract it on the fly with one coefficient
+// vector Cv (N) and store only the three gradient components per point (ld_p = 3, ld_c = 1): the gradient of the fitted
+// parameter, never materialising 3N values per point.
+template <int LCAP, int KCAP, bool CONTRACT>
 __global__ __launch_bounds__(BLOCK) void k_grad_sph(SphDev M, int64_t P, const double* __restrict__ lat,
                                                     const double* __restrict__ lon, const double* __restrict__ alt,
-                                                    double* __restrict__ Gout, int64_t ld_p, int64_t ld_c, int64_t ld_n)
+                                                    const double* __restrict__ Cv, double* __restrict__ Gout,
+                                                    int64_t ld_p, int64_t ld_c, int64_t ld_n)
 {
+    double az = 0.0, at = 0.0, ap = 0.0;
     const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t pc = p < P ? p : P - 1;
     const bool active = p < P;
@@ -211,7 +216,14 @@ __global__ __launch_bounds__(BLOCK) void k_grad_sph(SphDev M, int64_t P, const d
                             const double tp = e * Q0 * dtrig * inv_hr;
 #pragma unroll
                             for (int k = 0; k < KCAP; ++k) {
-                                if (k < maxk && active) {
+                                if (CONTRACT) {
+                                    if (k < maxk) {
+                                        const double cf = Cv[k * L2 + r];
+                                        az = fma(tz * (L0[k] + 2.0 * L1[k]), cf, az);
+                                        at = fma(tt * L0[k], cf, at);
+                                        ap = fma(tp * L0[k], cf, ap);
+                                    }
+                                } else if (k < maxk && active) {
                                     double* o = Gp + (int64_t)(k * L2 + r) * ld_n;
                                     o[0] = tz * (L0[k] + 2.0 * L1[k]);
                                     o[ld_c] = tt * L0[k];
@@ -223,6 +235,11 @@ __global__ __launch_bounds__(BLOCK) void k_grad_sph(SphDev M, int64_t P, const d
                 }
             }
         }
+    }
+    if (CONTRACT && active) {
+        Gp[0] = az;
+        Gp[ld_c] = at;
+        Gp[2 * ld_c] = ap;
     }
 }
 
@@ -786,11 +803,42 @@ extern "C" int vi_grad_basis_f64(vi_model* m, int64_t P, const double* d_lat, co
     const int L = m->sph.maxl, K = m->sph.maxk;
     const dim3 grid(nblocks(P, BLOCK)), block(BLOCK);
     if (L <= 6 && K <= 4)
-        hipLaunchKernelGGL((k_grad_sph<6, 4>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, d_G, ld_p, ld_c, ld_n);
+        hipLaunchKernelGGL((k_grad_sph<6, 4, false>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, nullptr,
+                           d_G, ld_p, ld_c, ld_n);
     else if (L <= 12 && K <= 8)
-        hipLaunchKernelGGL((k_grad_sph<12, 8>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, d_G, ld_p, ld_c, ld_n);
+        hipLaunchKernelGGL((k_grad_sph<12, 8, false>), grid, block, 0, m->ctx->stream, m->sph, P, d_lat, d_lon, d_alt, nullptr,
+                           d_G, ld_p, ld_c, ld_n);
     else {
         vi_set_error("vi_grad_basis_f64: order MAXL=%d MAXK=%d beyond the compiled limits (12, 8)", L, K);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+// Gradient of the fitted parameter: out[q][c] = sum_n grad_basis[q][c][n] * C[n], c = z, theta, phi components
+// (sphharmlag.py:148-184 contracted with one coefficient vector; the (Q, 3, N) array is never formed).
+extern "C" int vi_eval_grad_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                                const double* d_C, double* d_out)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_C && d_out, "null argument");
+    VI_REQUIRE(Q >= 0, "negative point count");
+    if (m->kind != VI_MODEL_SPHHARMLAG || !m->sph.scale1 || !m->sph.nu) {
+        vi_set_error("vi_eval_grad_f64: only the sphharmlag model provides a gradient basis");
+        return VI_ERR_UNSUPPORTED;
+    }
+    if (Q == 0) return VI_OK;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    const int L = m->sph.maxl, K = m->sph.maxk;
+    const dim3 grid(nblocks(Q, BLOCK)), block(BLOCK);
+    if (L <= 6 && K <= 4)
+        hipLaunchKernelGGL((k_grad_sph<6, 4, true>), grid, block, 0, m->ctx->stream, m->sph, Q, d_lat, d_lon, d_alt, d_C, d_out,
+                           (int64_t)3, (int64_t)1, (int64_t)0);
+    else if (L <= 12 && K <= 8)
+        hipLaunchKernelGGL((k_grad_sph<12, 8, true>), grid, block, 0, m->ctx->stream, m->sph, Q, d_lat, d_lon, d_alt, d_C, d_out,
+                           (int64_t)3, (int64_t)1, (int64_t)0);
+    else {
+        vi_set_error("vi_eval_grad_f64: order MAXL=%d MAXK=%d beyond the compiled limits (12, 8)", L, K);
         return VI_ERR_UNSUPPORTED;
     }
     VI_HIP(hipGetLastError());

@@ -112,6 +112,35 @@ class Estimate(object):
                                              out.ctypes.data_as(P)), 'vi_eval_f64_host')
         return out
 
+    def gradient(self, time, gdlat, gdlon, gdalt, check_hull=True):
+        """Gradient of the fitted parameter at the points: array of shape gdlat.shape + (3,), components along the
+        model coordinates z, theta, phi exactly as ``Model.grad_basis`` defines them (sphharmlag.py:148-184), NaN outside
+        the hull.  This is the output the reference's ``__call__`` advertises as ``calcgrad`` but never computes (the
+        code after its ``return`` is dead, estimate.py:125-147); ``__call__`` itself keeps ignoring the flag,
+        as the reference does."""
+        C, dC = self.get_C(time)
+        gdlat = np.asarray(gdlat, dtype=np.float64)
+        lat = np.ascontiguousarray(gdlat.ravel())
+        lon = np.ascontiguousarray(np.asarray(gdlon, dtype=np.float64).ravel())
+        alt = np.ascontiguousarray(np.asarray(gdalt, dtype=np.float64).ravel())
+        if not (lat.size == lon.size == alt.size):
+            raise ValueError('gdlat, gdlon, gdalt must have the same shape')
+        Q = lat.size
+        out = np.empty((Q, 3))
+        if Q:
+            h = self.model.handle()
+            ctx = self.model._ctx
+            d = [ctx.to_device(a) for a in (lat, lon, alt)]
+            dC_ = ctx.to_device(np.ascontiguousarray(C, dtype=np.float64))
+            dout = ctx.empty((Q, 3))
+            _lib.check(_lib.lib.vi_eval_grad_f64(h, Q, d[0].ptr, d[1].ptr, d[2].ptr, dC_.ptr, dout.ptr), 'vi_eval_grad_f64')
+            out = dout.download()
+            for a in d + [dC_, dout]:
+                a.free()
+            if check_hull:
+                out[~self.check_hull(lat, lon, alt)] = np.nan
+        return out.reshape(gdlat.shape + (3,))
+
     # estimate.py:153-178 (boolean mask, same shape as the inputs)
     def check_hull(self, lat0, lon0, alt0):
         alt0 = np.asarray(alt0, dtype=np.float64)
