@@ -118,6 +118,10 @@ int  vi_grad_basis_f64(vi_model* model, int64_t P, const double* d_lat, const do
  * (estimate.py:125-147, dead code there); the (Q, 3, N) array is never formed. */
 int  vi_eval_grad_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
                       const double* d_C, double* d_out);
+/* standard error of the fitted parameter, err[q] = sqrt(a_q^T dC a_q) with a_q the basis row of point q and dC the
+ * (N x N) coefficient covariance of the record: the `calcerr` output of the same dead branch (estimate.py:139-145) */
+int  vi_eval_err_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                     const double* d_dC, double* d_out);
 /* model coordinates (z, theta, phi) of sphharmlag.py:324-359 `transform_coord`; ECEF x,y,z for RBF */
 int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const double* d_lon,
                       const double* d_alt, double* d_c0, double* d_c1, double* d_c2);

@@ -23,4 +23,4 @@ from .sphharmlag import SphHarmLagOracle      # noqa: F401
 from .radbasfun import RadBasFunOracle        # noqa: F401
 from .fit import (eval_C, chi2objfunct, chi2_search, find_reg_param,   # noqa: F401
                   fit_records, compute_hull_vertices, gcvobjfunct, gcv_search)
-from .evaluate import get_C, check_hull, evaluate, evaluate_gradient   # noqa: F401
+from .evaluate import get_C, check_hull, evaluate, evaluate_gradient, evaluate_error   # noqa: F401

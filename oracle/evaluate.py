@@ -63,3 +63,15 @@ def evaluate_gradient(model, C, gdlat, gdlon, gdalt, hull_vert=None):
     if hull_vert is not None:
         out[~check_hull(hull_vert, gdlat.ravel(), np.asarray(gdlon).ravel(), np.asarray(gdalt).ravel())] = np.nan
     return out.reshape(gdlat.shape + (3,))
+
+
+def evaluate_error(model, dC, gdlat, gdlon, gdalt, hull_vert=None):
+    """Standard error of the fitted parameter by first-order propagation of the coefficient covariance:
+    sqrt(a^T dC a) per point (the `calcerr` output of the dead branch, estimate.py:139-145).  Shape of gdlat."""
+    gdlat = np.asarray(gdlat, dtype=np.float64)
+    A = model.basis(gdlat.ravel(), np.asarray(gdlon, dtype=np.float64).ravel(), np.asarray(gdalt, dtype=np.float64).ravel())
+    with np.errstate(invalid='ignore'):
+        out = np.sqrt(np.einsum('pn,nm,pm->p', A, np.asarray(dC, dtype=np.float64), A))
+    if hull_vert is not None:
+        out[~check_hull(hull_vert, gdlat.ravel(), np.asarray(gdlon).ravel(), np.asarray(gdalt).ravel())] = np.nan
+    return out.reshape(gdlat.shape)

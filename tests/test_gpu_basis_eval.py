@@ -277,3 +277,33 @@ def test_estimate_gradient_vs_oracle(tag):
     G = es.model.grad_basis(grid[0].ravel(), grid[1].ravel(), grid[2].ravel())
     assert rel(g.reshape(-1, 3), np.einsum('pcn,n->pc', G, C)) <= 1e-12
     assert es.gradient(t_mid, grid[0][:0, 0, 0], grid[1][:0, 0, 0], grid[2][:0, 0, 0]).shape == (0, 3)
+
+
+def test_estimate_error_vs_oracle():
+    """Estimate.error = sqrt(a^T dC a) (basis tile -> rocBLAS GEMM with the covariance -> row dot, vi_eval_err_f64) against
+    the oracle on the screened fixture, whose covariance is positive semidefinite to rounding; hull mask as __call__."""
+    import oracle
+    from volumetricinterp_amd import synth
+    f, es = _estimate('k8l2')
+    o = oracle.SphHarmLagOracle(maxk=8, maxl=2)
+    grid = synth.query_grid(6)
+    t_mid = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(np.mean(f['utime'][0])))
+    _, dC = oracle.get_C(t_mid, f['utime'], f['Coeffs'], f['Covariance'])
+    e = es.error(t_mid, *grid, check_hull=False)
+    ref = oracle.evaluate_error(o, dC, *grid)
+    assert e.shape == (6, 6, 6)
+    ok = np.isfinite(ref)
+    assert ok.sum() > 100 and np.array_equal(np.isfinite(e), ok)
+    assert rel(e[ok], ref[ok]) <= 1e-8
+    eh = es.error(t_mid, *grid)
+    refh = oracle.evaluate_error(o, dC, *grid, hull_vert=f['hull_vert'])
+    assert np.array_equal(np.isnan(eh), np.isnan(refh))
+    # many points: more than one 65 536-point chunk
+    rng = np.random.default_rng(2)
+    Q = 70001
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
+    big = es.error(t_mid, lat, lon, alt, check_hull=False)
+    sub = slice(65000, 65600)
+    refb = oracle.evaluate_error(o, dC, lat[sub], lon[sub], alt[sub])
+    okb = np.isfinite(refb)
+    assert rel(big[sub][okb], refb[okb]) <= 1e-8

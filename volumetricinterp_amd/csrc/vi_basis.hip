@@ -845,6 +845,52 @@ extern "C" int vi_eval_grad_f64(vi_model* m, int64_t Q, const double* d_lat, con
     return VI_OK;
 }
 
+// Standard error of the fitted parameter from the coefficient covariance: err[q] = sqrt(a_q^T dC a_q), a_q = basis row
+// of point q (first-order error propagation; the `calcerr` output the reference's Estimate.__call__ advertises but never
+// computes, estimate.py:139-145).  Chunks of points: basis tile A (K1) -> B = A dC (rocBLAS fp64 GEMM, MFMA) ->
+// row-wise dot.  2 N^2 flop per point: MFMA-bound.
+namespace {
+__global__ void k_rowdot_sqrt(int64_t P, int N, const double* __restrict__ A, const double* __restrict__ B,
+                              double* __restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= P) return;
+    double acc = 0.0;
+    for (int n = lane; n < N; n += 64) acc = fma(A[p * N + n], B[p * N + n], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) out[p] = sqrt(acc);          // a negative variance (indefinite dC) gives NaN, as np.sqrt would
+}
+}  // namespace
+
+extern "C" int vi_eval_err_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                               const double* d_dC, double* d_out)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_dC && d_out, "null argument");
+    VI_REQUIRE(Q >= 0, "negative point count");
+    if (Q == 0) return VI_OK;
+    VI_HIP(hipSetDevice(m->ctx->device));
+    const int N = m->N;
+    const int64_t chunk = 1 << 16;
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(m->ctx, (size_t)2 * chunk * N * sizeof(double), &ws);
+    if (rc != VI_OK) return rc;
+    double* A = (double*)ws;
+    double* B = A + chunk * N;
+    const double one = 1.0, zero = 0.0;
+    for (int64_t q0 = 0; q0 < Q; q0 += chunk) {
+        const int64_t qc = (Q - q0) < chunk ? (Q - q0) : chunk;
+        rc = vi_basis_f64(m, qc, d_lat + q0, d_lon + q0, d_alt + q0, A, N, 1);            // row-major (qc, N)
+        if (rc != VI_OK) return rc;
+        // row-major B (qc x N) = A (qc x N) dC (N x N)  <=>  column-major B^T (N x qc) = dC^T (N x N) A^T (N x qc)
+        VI_ROCBLAS(rocblas_dgemm(m->ctx->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)qc, N, &one,
+                                 d_dC, N, A, N, &zero, B, N));
+        hipLaunchKernelGGL(k_rowdot_sqrt, dim3(nblocks(qc, 4)), dim3(256), 0, m->ctx->stream, qc, N, A, B, d_out + q0);
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
 extern "C" int vi_transform_f64(vi_model* m, int64_t P, const double* d_lat, const double* d_lon, const double* d_alt,
                                 double* d_c0, double* d_c1, double* d_c2)
 {

@@ -141,6 +141,33 @@ class Estimate(object):
                 out[~self.check_hull(lat, lon, alt)] = np.nan
         return out.reshape(gdlat.shape + (3,))
 
+    def error(self, time, gdlat, gdlon, gdalt, check_hull=True):
+        """Standard error of the fitted parameter at the points, sqrt(a^T dC a) with a the basis row of the point and dC
+        the coefficient covariance of the record (first-order error propagation): the ``calcerr`` output the reference
+        advertises but never computes (estimate.py:139-145).  Same shape as gdlat, NaN outside the hull."""
+        C, dC = self.get_C(time)
+        gdlat = np.asarray(gdlat, dtype=np.float64)
+        lat = np.ascontiguousarray(gdlat.ravel())
+        lon = np.ascontiguousarray(np.asarray(gdlon, dtype=np.float64).ravel())
+        alt = np.ascontiguousarray(np.asarray(gdalt, dtype=np.float64).ravel())
+        if not (lat.size == lon.size == alt.size):
+            raise ValueError('gdlat, gdlon, gdalt must have the same shape')
+        Q = lat.size
+        out = np.empty(Q)
+        if Q:
+            h = self.model.handle()
+            ctx = self.model._ctx
+            d = [ctx.to_device(a) for a in (lat, lon, alt)]
+            ddC = ctx.to_device(np.ascontiguousarray(dC, dtype=np.float64))
+            dout = ctx.empty((Q,))
+            _lib.check(_lib.lib.vi_eval_err_f64(h, Q, d[0].ptr, d[1].ptr, d[2].ptr, ddC.ptr, dout.ptr), 'vi_eval_err_f64')
+            out = dout.download()
+            for a in d + [ddC, dout]:
+                a.free()
+            if check_hull:
+                out[~self.check_hull(lat, lon, alt)] = np.nan
+        return out.reshape(gdlat.shape)
+
     # estimate.py:153-178 (boolean mask, same shape as the inputs)
     def check_hull(self, lat0, lon0, alt0):
         alt0 = np.asarray(alt0, dtype=np.float64)
