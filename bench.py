@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument('--grid', type=int, default=128, help='query grid edge (128 -> 128^3 points)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval-many', action='store_true', help='skip the secondary many-timesteps evaluation figure')
+    ap.add_argument('--no-batched', action='store_true', help='skip the secondary batched-records figure (configs[2])')
     return ap.parse_args()
 
 
@@ -194,6 +195,35 @@ def main():
                 'note': 'algorithmic flops 2N per point-timestep (the contraction only; the recurrence is VALU work on '
                         'top); fp64 MFMA and fp64 VALU share one 78.6 TF peak on gfx950 and do not co-execute'}
 
+    # ---- secondary figure (not part of `value`): configs[2]-style batch - many records of one geometry fitted in one
+    #      batch and all evaluated on the same grid (the single-record step above keeps one CU of 256 busy)
+    batched = None
+    if rank == 0 and not args.no_batched:
+        Tb = 256
+        vb, eb = synth.synth_records(A, Tb, seed0=5000)
+        engb = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
+        engb.upload_records(eb**-2., vb)
+        dCb = ctx.empty((Tb, N))
+        dob = ctx.empty((Tb, Q))
+        ctx.sync()
+        tb0 = time.perf_counter()
+        resb = engb.fit_resident([P] * Tb, calccov=True)
+        dCb.upload(np.nan_to_num(resb['Coeffs']))
+        tb1 = time.perf_counter()
+        _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tb, dCb.ptr, None, 0, 0., dob.ptr),
+                   'vi_eval_f64')
+        ctx.sync()
+        tb2 = time.perf_counter()
+        ocb = resb['search']['curvature']['outcomes']
+        batched = {'records': Tb, 'fit_ms': (tb1 - tb0) * 1e3, 'eval_ms': (tb2 - tb1) * 1e3,
+                   'records_per_sec': Tb / (tb2 - tb0), 'points_per_sec': Tb * Q / (tb2 - tb0),
+                   'outcomes': {o_: ocb.count(o_) for o_ in set(ocb)},
+                   'note': 'single pass without warm-up: %d records of the bench geometry fitted as one batch (chi2 search, '
+                           'covariance) and each evaluated on the %d^3 grid' % (Tb, args.grid)}
+        dob.free()
+        dCb.free()
+        engb.close()
+
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
         traffic = None                 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
@@ -244,6 +274,8 @@ def main():
                 'frac_note': 'of the whole-chip fp64 peak; a launch of B systems can occupy min(B, 256) of 256 CUs'}
         if many is not None:
             out['eval_many_timesteps'] = many
+        if batched is not None:
+            out['batched_records'] = batched
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
         elif world == 1:
