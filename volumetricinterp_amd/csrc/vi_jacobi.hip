@@ -299,6 +299,35 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
             VI_STAMP(4);
         }
         if (!__syncthreads_or(rotated)) { ++sweep; break; }
+        // The iteration ends with a sweep that rotates nothing - 2m - 1 rounds of pure data movement (a quarter of a
+        // warm solve).  That sweep applies the rotation criterion to every pair of an unchanged matrix, so its outcome
+        // is known now: test all pairs in place (each thread its own blocks, ~2 us) and stop if none would rotate.  The
+        // slot arrangement after a whole sweep is the initial one, so nothing else changes (results bit-identical).
+        {
+            int viol = 0;
+            const int dg = 4 * nblk;                    // diagonal of slot 2P + a: A[dg + (a ? m + P : P)]
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const double apq = A[src[it][2 * a + b2]];
+                        const double app = A[dg + (a ? m + bP[it] : bP[it])];
+                        const double aqq = A[dg + (b2 ? m + bQ[it] : bQ[it])];
+                        const double aa = fabs(apq);
+                        const bool tiny = fmax(fmax(fabs(app), fabs(aqq)), aa) < drop;
+                        viol |= (aa * aa > eps2 * fabs(app * aqq) && aa > abs_floor && !tiny) ? 1 : 0;
+                    }
+            }
+            if (tid < m) {
+                const double app = A[spp], aqq = A[sqq], apq = A[spq];
+                const double aa = fabs(apq);
+                const bool tiny = fmax(fmax(fabs(app), fabs(aqq)), aa) < drop;
+                viol |= (aa * aa > eps2 * fabs(app * aqq) && aa > abs_floor && !tiny) ? 1 : 0;
+            }
+            if (!__syncthreads_or(viol)) { ++sweep; break; }
+        }
     }
     // ---- truncated solve in the eigenbasis (slot order) ---------------------------------------------
     double* yc = yv + ycur * Np;
