@@ -193,10 +193,11 @@ def test_eval_matrix_core_tiles_vs_oracle(tag, maxk, maxl):
     assert rel(outh[ok], out[ok]) == 0.0                                # same kernel, masked stores only
 
 
-@pytest.mark.parametrize('maxk,maxl,cap', [(4, 3, 10.), (2, 12, 15.), (4, 6, 12.7)])
+@pytest.mark.parametrize('maxk,maxl,cap', [(4, 3, 10.), (2, 12, 15.), (8, 12, 15.), (4, 6, 12.7)])
 def test_eval_matrix_core_other_orders_vs_oracle(maxk, maxl, cap):
     """Other orders through the multi-timestep dispatch: MAXL 3 x MAXK 4 (matrix-core kernel, integer degrees); MAXL 12 x
-    MAXK 2 at CAP_LIM 15 (half-integer degrees, 2F1 seeds; no matrix-core instantiation: VALU tiles; at CAP_LIM 10 this
+    MAXK 2 and the configs[4] order MAXL 12 x MAXK 8 at CAP_LIM 15 (half-integer degrees, 2F1 seeds; the high-order kernel
+    k_eval_sph_split with the chains in two groups; at CAP_LIM 10 this
     order overflows Kvm, F8, and every density is NaN as in the reference); and CAP_LIM 12.7 (several degree groups: the
     generic kernel)."""
     import oracle

@@ -753,6 +753,8 @@ struct EvalTimer {
 }  // namespace
 int vi_eval_sph_mfma(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
                      const double* Cp, const unsigned char* hull, int F, double* out, int64_t* done);
+int vi_eval_sph_split(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
+                      const double* Cp, const unsigned char* hull, int F, double* out, int* handled);
 namespace {
 
 bool use_fast_eval()
@@ -967,6 +969,11 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         const int64_t Tr = T - done;
         const double* coef = m->d_coef + done * N;
         double* outp = d_out + done * Q;
+        if (use_fast_eval()) {                  // high orders: the chains in groups (vi_eval_split.hip)
+            int handled = 0;
+            const int rc = vi_eval_sph_split(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, (int)F, outp, &handled);
+            if (rc != VI_OK || handled) return rc;
+        }
         if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
 #define VI_FAST(LL, KK) \
     if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp)
