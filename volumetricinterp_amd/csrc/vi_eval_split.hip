@@ -275,6 +275,7 @@ int vi_eval_sph_split(vi_model* m, int64_t Q, const double* lat, const double* l
     else if (L == 12 && K == 8 && nh == 4) rc = launch_split<12, 8, 4>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
     else if (L == 12 && K == 8) rc = launch_split<12, 8, 3>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
     else if (L == 12 && K == 2) rc = launch_split<12, 2, 3>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+    // (the default order gains nothing from groups: 0.155 ms at once, 0.171 / 0.165 ms in two / three groups)
     else return VI_OK;
     if (rc == VI_OK) *handled = 1;
     return rc;
