@@ -493,25 +493,31 @@ __global__ __launch_bounds__(JBS) void k_jacobi_vectors(int N, const double2* __
     }
 }
 
-// Latency variant for FEW systems (a single record's prepare / final solve): one WAVE per column, the column in the
-// wave's registers (WaveReplay) - no LDS, no barrier.  N independent single-wave workgroups per system spread over as
-// many CUs.  Even N <= 256 only.
+// Eigenvectors by register replay: one WAVE per strip of CPW columns, the columns in the wave's registers (WaveReplay)
+// - no LDS, no barrier.  CPW = 1 for a single system (N independent waves spread over as many CUs: latency); CPW = 8 for
+// batches, so that a system's rotation log is read N / 8 times instead of N times.  Even N <= 256 only.
+template <int CPW>
 __global__ __launch_bounds__(64) void k_jacobi_vectors_wave(int N, const double2* __restrict__ rotlog, int64_t log_stride,
                                                             const int* __restrict__ nround_in, double* __restrict__ Vout)
 {
     const int m = N >> 1;
     const int lane = threadIdx.x;
-    const int64_t sys = blockIdx.x;
-    const int col = blockIdx.y;                         // final slot whose eigenvector this wave builds
+    const int64_t sys = blockIdx.y;
+    const int col0 = blockIdx.x * CPW;                  // final slots whose eigenvectors this wave builds
     const double2* logp = rotlog + sys * log_stride;
     const int64_t nround = nround_in[sys];
-    WaveReplay W;
-    W.init(lane, m);
-    W.t0 = (2 * lane == col) ? 1.0 : 0.0;
-    W.b0 = (2 * lane + 1 == col) ? 1.0 : 0.0;
-    W.t1 = (2 * (lane + 64) == col) ? 1.0 : 0.0;
-    W.b1 = (2 * (lane + 64) + 1 == col) ? 1.0 : 0.0;
+    WaveReplay W[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int col = col0 + c;
+        W[c].init(lane, m);
+        W[c].t0 = (2 * lane == col) ? 1.0 : 0.0;
+        W[c].b0 = (2 * lane + 1 == col) ? 1.0 : 0.0;
+        W[c].t1 = (2 * (lane + 64) == col) ? 1.0 : 0.0;
+        W[c].b1 = (2 * (lane + 64) + 1 == col) ? 1.0 : 0.0;
+    }
     constexpr int PF = 8;                               // rounds of (c, s) prefetched per batch
+    const bool has0 = lane < m, has1 = lane + 64 < m;
     for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
         const int nb = r1 >= PF ? PF : (int)r1;
         double2 pf0[PF], pf1[PF];
@@ -520,22 +526,30 @@ __global__ __launch_bounds__(64) void k_jacobi_vectors_wave(int N, const double2
             pf0[u] = make_double2(1.0, 0.0);
             pf1[u] = make_double2(1.0, 0.0);
             if (u < nb) {
-                if (W.has0) pf0[u] = logp[(r1 - 1 - u) * m + lane];
-                if (W.has1) pf1[u] = logp[(r1 - 1 - u) * m + lane + 64];
+                if (has0) pf0[u] = logp[(r1 - 1 - u) * m + lane];
+                if (has1) pf1[u] = logp[(r1 - 1 - u) * m + lane + 64];
             }
         }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (u < nb) W.round(pf0[u], pf1[u]);
+            if (u < nb) {
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) W[c].round(pf0[u], pf1[u]);
+            }
     }
-    double* Vo = Vout + sys * (int64_t)N * N + (int64_t)col * N;     // eigenvector `col`, indexed by original index
-    if (W.has0) {
-        Vo[slot_orig0(2 * lane, m)] = W.t0;
-        Vo[slot_orig0(2 * lane + 1, m)] = W.b0;
-    }
-    if (W.has1) {
-        Vo[slot_orig0(2 * (lane + 64), m)] = W.t1;
-        Vo[slot_orig0(2 * (lane + 64) + 1, m)] = W.b1;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int col = col0 + c;
+        if (col >= N) break;
+        double* Vo = Vout + sys * (int64_t)N * N + (int64_t)col * N;     // eigenvector `col`, indexed by original index
+        if (has0) {
+            Vo[slot_orig0(2 * lane, m)] = W[c].t0;
+            Vo[slot_orig0(2 * lane + 1, m)] = W[c].b0;
+        }
+        if (has1) {
+            Vo[slot_orig0(2 * (lane + 64), m)] = W[c].t1;
+            Vo[slot_orig0(2 * (lane + 64) + 1, m)] = W[c].b1;
+        }
     }
 }
 
@@ -668,11 +682,16 @@ int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sw
         const char* e = getenv("VINTERP_VECTORS");
         wave_ok = (e && !strcmp(e, "block")) ? 0 : 1;
     }
-    if (wave_ok && N <= 256 && (N % 2) == 0 && B * N <= 2 * c->n_cu) {
+    if (wave_ok && N <= 256 && (N % 2) == 0) {
         const int m = N / 2;
         const int64_t log_stride = (int64_t)max_sweeps * (N - 1) * m;
-        hipLaunchKernelGGL(k_jacobi_vectors_wave, dim3((unsigned)B, (unsigned)N), dim3(64), 0, c->stream, N,
-                           (const double2*)d_log, log_stride, d_nround, d_V);
+        // the strips of one system are neighbours in the grid (x fastest), so they read its log together through L2
+        if (B * N <= 2 * c->n_cu)
+            hipLaunchKernelGGL(k_jacobi_vectors_wave<1>, dim3((unsigned)N, (unsigned)B), dim3(64), 0, c->stream, N,
+                               (const double2*)d_log, log_stride, d_nround, d_V);
+        else
+            hipLaunchKernelGGL(k_jacobi_vectors_wave<8>, dim3((unsigned)((N + 7) / 8), (unsigned)B), dim3(64), 0, c->stream, N,
+                               (const double2*)d_log, log_stride, d_nround, d_V);
         VI_HIP(hipGetLastError());
         return VI_OK;
     }
