@@ -3,11 +3,15 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input: fit ONE record
 (26 beams x 100 ranges, default order MAXK=4 MAXL=6 -> N=144, curvature regularisation, chi^2 search,
-covariance) and evaluate the fitted model on a 128^3 geodetic query grid (BASELINE.json configs[1]).
-Inputs (beam geometry, weights/data, query grid, regularisation matrix) are resident in HBM before the
+covariance) and evaluate the fitted model on a 128^3 geodetic query grid with the convex-hull mask on
+(the reference's default check_hull=True) - BASELINE.json configs[1].
+Inputs (beam geometry, weights/data, query grid, regularisation matrix, hull facets) are resident in HBM before the
 timed region; outputs stay on the device.  With --gpus N > 1 every rank runs the same per-GPU workload on
 its own records (independent timesteps: weak scaling, no data-path collective); shared parameters are
 broadcast once from rank 0 over RCCL before the timed region.
+
+`python bench.py --gpus N` without a torchrun environment starts N child processes itself (one per device, before
+anything touches a GPU) and prints the line rank 0 produced.
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,6 +20,8 @@ import ctypes as C
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +34,15 @@ if REPO not in sys.path:
 CFG = ('[DEFAULT]\nREGULARIZATION_LIST = curvature\nREGULARIZATION_METHOD = chi2\n'
        '[MODEL]\nNAME = sphharmlag\nMAXK = 4\nMAXL = 6\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\nLONCP = 262\n')
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-FP64_VALU_PEAK_TF = 78.6       # fp64 vector peak
+# ---- roofline constants (MI355X_MICROARCH.md) --------------------------------------------------------------
+HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TF = 78.6            # fp64 vector = fp64 matrix peak (one set of DP units)
+N_CU = 256
+CLOCK_GHZ = 2.4
+# LDS, per CU: ds_read_b64 256 B/clk, ds_write_b64 ~85 B/clk.  A Jacobi round moves every byte of the matrix once out
+# of and once back into LDS, so the combined rate for equal read and write volumes is 2 / (1/256 + 1/85) B/clk.
+LDS_RW_BYTES_PER_CLK_CU = 2. / (1. / 256. + 1. / 85.)
+LDS_PEAK_GBS = LDS_RW_BYTES_PER_CLK_CU * CLOCK_GHZ * N_CU          # ~78 TB/s, all 256 CUs streaming
 EVAL_BYTES_PER_POINT = 32.0    # 3 x 8 B coordinates in + 8 B density out
 EVAL_FLOPS_PER_POINT = 3.0e3   # SURVEY 8d E1 estimate at the default order
 
@@ -43,62 +56,158 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval-many', action='store_true', help='skip the secondary many-timesteps evaluation figure')
     ap.add_argument('--no-batched', action='store_true', help='skip the secondary batched-records figure (configs[2])')
+    ap.add_argument('--batched-records', type=int, default=1000, help='records of the configs[2] figure')
     return ap.parse_args()
 
 
-def cpu_baseline(lat, lon, alt, value, error, R, grid_n):
-    """The oracle (faithful CPU restatement of the reference) on a bounded sample of the same workload:
-    the full one-record fit, and a 16^3 sub-grid of the query evaluation scaled to grid_n^3 points."""
-    import oracle                                  # checker / baseline only - never the measured GPU path
-    from volumetricinterp_amd import synth
-    import contextlib
+# ---- --gpus N without a launcher: start the ranks ourselves ---------------------------------------------------
+def spawn_ranks(n):
+    """Start n fresh copies of this script, one per device (RANK = LOCAL_RANK = i), wait for them and relay rank 0's
+    line.  Runs before anything in this process has touched a GPU (no HIP call, no library load): children are
+    ordinary subprocesses, nothing is exec'ed over an initialised runtime."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _cpu_worker(job):
+    """One worker of the all-cores run: the faithful oracle fit of one record + a hull-masked evaluation of a
+    sub-grid.  Runs in a fresh process (spawn) with one BLAS thread."""
+    seed, sub, variant = job
     import warnings
+    import oracle                                  # checker / baseline only - never the measured GPU path
+    from oracle import fit_fast
+    from volumetricinterp_amd import synth
     try:
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
+        threadpool_limits(limits=1)
     except Exception:                              # pragma: no cover
-        limiter = contextlib.nullcontext()
+        pass
     model = oracle.SphHarmLagOracle()
-    with limiter, warnings.catch_warnings():
+    lat, lon, alt = synth.beams(*synth.GEOM_C2, seed=0)
+    R = np.load(os.path.join(REPO, 'tests', 'golden', 'regmat.npz'))['default_curvature']
+    with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        t0 = time.perf_counter()
+        A = model.basis(lat, lon, alt)
+        b, err, _ = synth.synth_record(A, seed)
         counter = [0]
-        C, dC, c2, params = oracle.fit_records(model, lat, lon, alt, value[:1], error[:1], {'curvature': R},
-                                               ['curvature'], counter)
+        t0 = time.perf_counter()
+        if variant == 'faithful':
+            Cf, _, _, _ = oracle.fit_records(model, lat, lon, alt, b[None], err[None], {'curvature': R}, ['curvature'],
+                                             counter)
+            Cv = Cf[0]
+        else:
+            Cv, _, _, _ = fit_fast.fit_record(A, b, err**-2., R, counter)
         t_fit = time.perf_counter() - t0
-        sub = 16
         g = synth.query_grid(sub)
-        Cv = C[0] if np.all(np.isfinite(C[0])) else np.ones(model.nbasis)
+        hv = oracle.compute_hull_vertices(lat, lon, alt)
+        Cv = Cv if np.all(np.isfinite(Cv)) else np.ones(model.nbasis)
+        t0 = time.perf_counter()
+        oracle.evaluate(model, Cv, *g, hull_vert=hv)       # check_hull=True, one Qhull per point (estimate.py:153-178)
+        t_eval = time.perf_counter() - t0
         t0 = time.perf_counter()
         oracle.evaluate(model, Cv, *g)
-        t_eval_sub = time.perf_counter() - t0
+        t_eval_nohull = time.perf_counter() - t0
+    return dict(t_fit=t_fit, t_eval=t_eval, t_eval_nohull=t_eval_nohull, eval_C_calls=counter[0] + 1)
+
+
+def cpu_baseline(grid_n):
+    """The oracle (faithful CPU restatement of the reference, kind 'port') on a bounded sample of the same workload,
+    as BASELINE.md section 4 asks: one process, then `multiprocessing` over independent records on all host cores; plus
+    the optimised-CPU variant for context.  Sample per worker: the full one-record fit (26 x 100, N = 144) and a
+    hull-masked evaluation of a 12^3 sub-grid scaled to grid_n^3 points."""
+    import multiprocessing as mp
+    sub = 12
     Q = grid_n**3
-    t_eval = t_eval_sub * Q / sub**3
-    return dict(value=Q / (t_fit + t_eval), unit='points/s', cores=1, kind='port',
-                sample='oracle (NumPy/SciPy restatement, 1 BLAS thread): full fit of 1 record 26x100 N=144 '
-                       '(%d eval_C calls, %.1f s) + evaluation of a %d^3 sub-grid (%.2f s) scaled to %d^3 points'
-                       % (counter[0] + 1, t_fit, sub, t_eval_sub, grid_n),
-                fit_seconds=t_fit, eval_points_per_sec=sub**3 / t_eval_sub)
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu_avail = len(os.sched_getaffinity(0))
+    except AttributeError:                          # pragma: no cover
+        ncpu_avail = ncpu
+    # the GPU box gives a one-GPU job a 16-core share of the host whatever the affinity mask says
+    workers = max(1, int(os.environ.get("VINTERP_CPU_WORKERS", min(ncpu_avail, 16))))
+    ctxmp = mp.get_context('spawn')                 # fresh interpreters: nothing of the GPU runtime is inherited
+
+    def rate(r):
+        return Q / (r['t_fit'] + r['t_eval'] * Q / sub**3)
+    with ctxmp.Pool(1) as pool:
+        one = pool.map(_cpu_worker, [(1000, sub, 'faithful')])[0]
+        fast = pool.map(_cpu_worker, [(1000, sub, 'optimised')])[0]
+    t0 = time.perf_counter()
+    with ctxmp.Pool(workers) as pool:
+        many = pool.map(_cpu_worker, [(1000 + i, sub, 'faithful') for i in range(workers)], chunksize=1)
+    wall = time.perf_counter() - t0
+    all_rate = sum(rate(r) for r in many)           # every worker's own step rate under full load
+    return dict(value=all_rate, unit='points/s', cores=workers, kind='port',
+                sample='oracle (NumPy/SciPy restatement of the reference, one BLAS thread per process): %d processes, '
+                       'each the full fit of one 26x100 record at N=144 (%d eval_C calls, %.1f s alone, %.1f s mean under '
+                       'load) + a hull-masked (one Qhull per point) evaluation of a %d^3 sub-grid (%.2f s) scaled to '
+                       '%d^3 points; wall %.1f s'
+                       % (workers, one['eval_C_calls'], one['t_fit'], float(np.mean([r['t_fit'] for r in many])), sub,
+                          one['t_eval'], grid_n, wall),
+                host_cpu_count=ncpu, host_cpus_available=ncpu_avail, cpu_model=_cpu_model(), blas_threads_per_process=1,
+                single_process={'value': rate(one), 'cores': 1, 'fit_seconds': one['t_fit'],
+                                'eval_points_per_sec': sub**3 / one['t_eval'],
+                                'eval_points_per_sec_no_hull': sub**3 / one['t_eval_nohull'],
+                                'timesteps_per_sec': 1. / one['t_fit']},
+                optimised_single_process={'value': rate(fast), 'cores': 1, 'fit_seconds': fast['t_fit'],
+                                          'eval_C_calls': fast['eval_C_calls'],
+                                          'note': 'A^T W A once per record, chi^2(alpha) memoised across scale factors; '
+                                                  'same LAPACK calls on the same matrices (context only)'},
+                all_cores={'timesteps_per_sec': workers / float(np.mean([r['t_fit'] for r in many])),
+                           'fit_seconds_mean': float(np.mean([r['t_fit'] for r in many]))})
 
 
 def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     # The contract is ONE JSON line on stdout.  Libraries loaded below (RCCL prints a version banner on
     # communicator creation) write to file descriptor 1 directly, so keep a private handle on the real stdout
     # and point fd 1 at stderr for the rest of the run.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
-    args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('VINTERP_DEVICE', str(local_rank))
+    # CPU baseline first (rank 0, N = 1 only): its worker processes are started before this process has loaded the
+    # HIP runtime, and nothing runs on the GPU while the host cores are being timed
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.grid)
 
     from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.estimate import hull_equations
     from volumetricinterp_amd.fitengine import FitEngine
+    from volumetricinterp_amd.geodesy import geodetic2ecef
     from volumetricinterp_amd.models.sphharmlag import Model
-
     from volumetricinterp_amd.parallel import Comm
+    from scipy.spatial import ConvexHull
+
     ctx = _lib.get_context(local_rank)
     # control plane over a Unix socket + ncclBroadcast (RCCL over xGMI) for the shared parameters; no torch in
     # GPU processes (two HIP runtimes in one process crash).  VINTERP_DIST_BACKEND=socket skips RCCL, e.g. to
@@ -114,9 +223,14 @@ def main():
     shared = {}
     if rank == 0:
         lat, lon, alt = synth.beams(nb, nr, seed=0)
-        shared = dict(lat=lat, lon=lon, alt=alt, R=model.eval_reg_matricies['curvature']())
+        Rpts = np.array(geodetic2ecef(lat, lon, alt)).T
+        eq, tol = hull_equations(Rpts[ConvexHull(Rpts).vertices])          # interpolate.py:409-426 + estimate.py:153-178
+        shared = dict(lat=lat, lon=lon, alt=alt, R=model.eval_reg_matricies['curvature'](), hull_eq=eq,
+                      hull_tol=np.array([tol]))
     shared = comm.broadcast_arrays(shared)
     lat, lon, alt, R = shared['lat'], shared['lon'], shared['alt'], shared['R']
+    hull_eq, hull_tol = np.ascontiguousarray(shared['hull_eq']), float(shared['hull_tol'][0])
+    F = hull_eq.shape[0]
 
     # ---- per-rank inputs, made resident before the timed region -----------------------------------------
     dlat, dlon, dalt = ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(alt)
@@ -133,10 +247,16 @@ def main():
     g = synth.query_grid(args.grid)
     Q = g[0].size
     dq = [ctx.to_device(a.ravel()) for a in g]
+    dhull = ctx.to_device(hull_eq)
     dC = ctx.empty((T, N))
     dout = ctx.empty((T, Q))
 
     fit_ms, eval_ms = [], []
+
+    def eval_grid(dCx, Tx, doutx, hull=True):
+        _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tx, dCx.ptr,
+                                        dhull.ptr if hull else None, F if hull else 0, hull_tol if hull else 0.,
+                                        doutx.ptr), 'vi_eval_f64')
 
     def step(record=False):
         t0 = time.perf_counter()
@@ -146,13 +266,9 @@ def main():
             Cfit = np.nan_to_num(Cfit)
         dC.upload(Cfit)
         t1 = time.perf_counter()
-        ctx.timer_start()
-        _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, T, dC.ptr, None, 0, 0., dout.ptr),
-                   'vi_eval_f64')
-        ctx.timer_stop_ms()
-        kms = C.c_double(0.)                       # HIP events on the library's stream, right around the kernel
-        _lib.check(_lib.lib.vi_eval_kernel_ms(ctx.handle, C.byref(kms)), 'vi_eval_kernel_ms')
-        ems = kms.value
+        ctx.timer_start()                          # HIP events on the library's own stream, around the whole call
+        eval_grid(dC, T, dout, hull=True)          # hull mask on: the reference default (estimate.py:75)
+        ems = ctx.timer_stop_ms()
         if record:
             fit_ms.append((t1 - t0) * 1e3)
             eval_ms.append(ems)
@@ -173,113 +289,156 @@ def main():
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     st = ctx.solve_timing(0)
 
+    def kernel_ms(fn, reps=5):
+        best = float('inf')
+        for _ in range(reps):
+            fn()
+            kms = C.c_double(0.)                   # HIP events right around the evaluation kernel launches
+            _lib.check(_lib.lib.vi_eval_kernel_ms(ctx.handle, C.byref(kms)), 'vi_eval_kernel_ms')
+            best = min(best, kms.value)
+        return best
+
+    # ---- the evaluation kernel on its own (not part of `value`): with and without the hull pass ---------------------
+    ev_kernel_hull = ev_kernel_nohull = ev_call_nohull = float('nan')
+    if rank == 0:
+        ev_kernel_hull = kernel_ms(lambda: eval_grid(dC, T, dout, hull=True))
+        ev_kernel_nohull = kernel_ms(lambda: eval_grid(dC, T, dout, hull=False))
+        best = float('inf')
+        for _ in range(5):
+            ctx.timer_start()
+            eval_grid(dC, T, dout, hull=False)
+            best = min(best, ctx.timer_stop_ms())
+        ev_call_nohull = best
+
     # ---- secondary figure (not part of `value`): many timesteps on the same grid (SURVEY 8d row E2, configs[3]) ----
     many = None
     if rank == 0 and not args.no_eval_many:
         Tm = 64
         dCm = ctx.to_device(np.random.default_rng(3).standard_normal((Tm, N)))
         dom = ctx.empty((Tm, Q))
-        best = float('inf')
-        for _ in range(3):
-            _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tm, dCm.ptr, None, 0, 0., dom.ptr),
-                       'vi_eval_f64')
-            kms = C.c_double(0.)
-            _lib.check(_lib.lib.vi_eval_kernel_ms(ctx.handle, C.byref(kms)), 'vi_eval_kernel_ms')
-            best = min(best, kms.value)
+        best = kernel_ms(lambda: eval_grid(dCm, Tm, dom, hull=True), reps=3)
         dom.free()
         dCm.free()
         many = {'kernel': 'k_eval_sph_mfma<6,1,2> (v_mfma_f64_16x16x4)', 'timesteps': Tm, 'points': Q, 'ms': best,
-                'point_timesteps_per_sec': Q * Tm / (best * 1e-3), 'bound': 'mfma',
-                'achieved': 2. * N * Q * Tm / (best * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
-                'frac': 2. * N * Q * Tm / (best * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                'hull_mask': True, 'point_timesteps_per_sec': Q * Tm / (best * 1e-3), 'bound': 'mfma',
+                'achieved': 2. * N * Q * Tm / (best * 1e-3) / 1e12, 'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': 2. * N * Q * Tm / (best * 1e-3) / 1e12 / FP64_PEAK_TF,
                 'note': 'algorithmic flops 2N per point-timestep (the contraction only; the recurrence is VALU work on '
                         'top); fp64 MFMA and fp64 VALU share one 78.6 TF peak on gfx950 and do not co-execute'}
 
-    # ---- secondary figure (not part of `value`): configs[2]-style batch - many records of one geometry fitted in one
-    #      batch and all evaluated on the same grid (the single-record step above keeps one CU of 256 busy)
+    # ---- secondary figure (not part of `value`): BASELINE configs[2] - 1000 records of one geometry fitted as one
+    #      batch (the single-record step above keeps one CU of 256 busy).  One warm-up pass, one timed pass.
     batched = None
-    if rank == 0 and not args.no_batched:
-        Tb = 256
+    if rank == 0 and not args.no_batched and args.batched_records > 0:
+        Tb = args.batched_records
         vb, eb = synth.synth_records(A, Tb, seed0=5000)
         engb = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
         engb.upload_records(eb**-2., vb)
-        dCb = ctx.empty((Tb, N))
-        dob = ctx.empty((Tb, Q))
+        engb.fit_resident([P] * Tb, calccov=True)                    # warm-up (allocations, rocBLAS kernels)
+        ctx.solve_timing(1)
         ctx.sync()
         tb0 = time.perf_counter()
         resb = engb.fit_resident([P] * Tb, calccov=True)
-        dCb.upload(np.nan_to_num(resb['Coeffs']))
-        tb1 = time.perf_counter()
-        _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tb, dCb.ptr, None, 0, 0., dob.ptr),
-                   'vi_eval_f64')
         ctx.sync()
-        tb2 = time.perf_counter()
+        tb1 = time.perf_counter()
+        stb = ctx.solve_timing(0)
         ocb = resb['search']['curvature']['outcomes']
-        batched = {'records': Tb, 'fit_ms': (tb1 - tb0) * 1e3, 'eval_ms': (tb2 - tb1) * 1e3,
-                   'records_per_sec': Tb / (tb2 - tb0), 'points_per_sec': Tb * Q / (tb2 - tb0),
+        Te = min(Tb, 64)                                             # evaluation of a tile of the fitted records
+        dCb = ctx.to_device(np.nan_to_num(resb['Coeffs'][:Te]))
+        dob = ctx.empty((Te, Q))
+        evb = kernel_ms(lambda: eval_grid(dCb, Te, dob, hull=True), reps=2) * Tb / Te
+        lds_b = 2. * 8. * (N * (N + 1) // 2) * stb['rounds']
+        batched = {'records': Tb, 'fit_ms': (tb1 - tb0) * 1e3, 'records_per_sec_fit': Tb / (tb1 - tb0),
+                   'eval_ms_scaled': evb, 'records_per_sec': Tb / (tb1 - tb0 + evb * 1e-3),
+                   'points_per_sec': Tb * Q / (tb1 - tb0 + evb * 1e-3),
+                   'solves': stb['systems'], 'solve_launches': stb['launches'],
+                   'jacobi_kernel_ms': stb['total_ms'] * stb['launches'] / max(1, stb['timed']),
+                   'jacobi_lds_gbs': lds_b / max(1e-9, stb['total_ms'] * stb['launches'] / max(1, stb['timed']) * 1e-3) / 1e9,
+                   'jacobi_lds_frac': lds_b / max(1e-9, stb['total_ms'] * stb['launches'] / max(1, stb['timed']) * 1e-3) / 1e9
+                   / LDS_PEAK_GBS,
                    'outcomes': {o_: ocb.count(o_) for o_ in set(ocb)},
-                   'note': 'single pass without warm-up: %d records of the bench geometry fitted as one batch (chi2 search, '
-                           'covariance) and each evaluated on the %d^3 grid' % (Tb, args.grid)}
+                   'redone_cold': len(resb['search']['curvature'].get('redone_cold', [])),
+                   'note': 'configs[2]: %d records of the bench geometry fitted as one batch (chi2 search, covariance), '
+                           'timed pass after one warm-up pass; evaluation of %d of them on the %d^3 grid (hull mask on), '
+                           'scaled to all' % (Tb, Te, args.grid)}
         dob.free()
         dCb.free()
         engb.close()
 
     if rank == 0:
         ev = float(np.mean(eval_ms)) if eval_ms else float('nan')
-        traffic = None                 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+        traffic_eval = None            # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
         try:
             pmc = json.load(open(os.path.join(REPO, 'profiles', 'r1_eval_pmc.json')))
             if pmc.get('points_per_launch') == Q * T:
-                traffic = pmc['hbm_bytes_per_launch']
+                traffic_eval = pmc['hbm_bytes_per_launch']
         except Exception:
             pass
         pts = args.steps * Q * T * world
+        info0 = res['search']['curvature']['info'][0] if res['search']['curvature']['info'] else {}
         out = {
             'metric': 'fit+eval query-points/sec', 'value': pts / elapsed, 'unit': 'points/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: per GPU 1 record, 26-beam x 100-range fit (N=144, curvature, chi2 '
-                                   'search, covariance) + %d^3 geodetic query grid, fp64' % args.grid,
+                                   'search, covariance) + %d^3 geodetic query grid with the hull mask, fp64' % args.grid,
                        'points_per_step_per_gpu': Q * T, 'timesteps_per_step_per_gpu': T},
             'timesteps_per_sec': args.steps * T * world / elapsed,
-            'breakdown_ms': {'fit': float(np.mean(fit_ms)), 'eval_kernel': ev,
+            'breakdown_ms': {'fit': float(np.mean(fit_ms)), 'eval_call_hull_on': ev,
                              'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
                              'fit_outcome': res['search']['curvature']['outcomes'],
-                             'root_finder': [i.get('finder') for i in res['search']['curvature']['info']]},
+                             'root_finder': [i.get('finder') for i in res['search']['curvature']['info']],
+                             'brent_iterations': info0.get('iterations'),
+                             'consistent': info0.get('consistent'), 'redone_cold': info0.get('redone_cold', False)},
             'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
             'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
-            'roofline': {'kernel': 'k_eval_sph_fast<6,4,1>', 'bound': 'hbm',
-                         'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'traffic': traffic,
-                         'note': 'fused eval is fp64-VALU-bound (AI ~94 flop/B): %.2f of the %.1f TF fp64 vector peak '
-                                 'at ~3.0 kflop/point' % (EVAL_FLOPS_PER_POINT * Q * T / (ev * 1e-3) / 1e12
-                                                          / FP64_VALU_PEAK_TF, FP64_VALU_PEAK_TF)},
         }
-        # the kernel the step actually spends its time in (latency-bound small-matrix
-        # factorisations, neither HBM nor MFMA): one 512-thread workgroup = one CU per system, so a single-record
-        # step can occupy 1 of 256 CUs during the ~15 dependent root-finder solves
+        # ---- roofline of the kernel that dominates the step: the in-LDS Jacobi eigen-solve (K3).  Neither HBM nor
+        #      MFMA bound it: the matrix lives in one CU's LDS and every round moves it once through the registers.
+        #      Algorithmic bytes: 2 (read + write) x 8 B x N(N+1)/2 per round and system; rounds are
+        #      counted by the kernel itself; durations are HIP events around every launch of the timed steps.
         if st['timed']:
-            flops = 10. * N**3 * st['systems'] * st['timed'] / max(1, st['launches'])
-            out['fit_kernel'] = {
-                'kernel': 'k_jacobi_solve<5>', 'launches_per_step': st['launches'] / args.steps,
-                'systems_per_step': st['systems'] / args.steps, 'avg_launch_ms': st['total_ms'] / st['timed'],
-                'max_launch_ms': st['max_ms'], 'ms_per_step': st['total_ms'] / st['timed'] * st['launches'] / args.steps,
-                'share_of_step': st['total_ms'] / st['timed'] * st['launches'] / (elapsed * 1e3),
-                'bound': 'LDS-resident eigen-solve, one CU per system (latency-bound at 1 record)',
-                'achieved_gflops': flops / (st['total_ms'] * 1e-3) / 1e9, 'flops_model': '10 N^3 per solve (SURVEY 8d F2)',
-                'peak_gflops': FP64_VALU_PEAK_TF * 1e3,
-                'frac': flops / (st['total_ms'] * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                'frac_note': 'of the whole-chip fp64 peak; a launch of B systems can occupy min(B, 256) of 256 CUs'}
+            avg_ms = st['total_ms'] / st['timed']
+            launches_per_step = st['launches'] / args.steps
+            lds_bytes_per_launch = 2. * 8. * (N * (N + 1) // 2) * st['rounds'] / max(1, st['launches'])
+            flops_per_launch = 10. * N**3 * st['systems'] / max(1, st['launches'])
+            ach = lds_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            sys_per_launch = st['systems'] / max(1, st['launches'])
+            out['roofline'] = {
+                'kernel': 'k_jacobi_solve', 'bound': 'lds', 'achieved': ach, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
+                'frac': ach / LDS_PEAK_GBS, 'traffic': None,
+                'traffic_note': 'HBM traffic is not the resource: per system 166 KB in, ~1.3 MB of rotation log out and '
+                                'back, against ~0.1-0.5 GB through LDS',
+                'launches_per_step': launches_per_step, 'systems_per_launch': sys_per_launch,
+                'avg_launch_ms': avg_ms, 'max_launch_ms': st['max_ms'], 'ms_per_step': avg_ms * launches_per_step,
+                'share_of_step': avg_ms * launches_per_step / (elapsed / args.steps * 1e3),
+                'rounds_per_system': st['rounds'] / max(1, st['systems']),
+                'peak_note': 'chip-wide LDS rate for equal read and write volumes: %.0f B/clk/CU x %.1f GHz x %d CUs; one '
+                             'system occupies one CU, so a launch of B systems can reach at most min(B,256)/256 of it'
+                             % (LDS_RW_BYTES_PER_CLK_CU, CLOCK_GHZ, N_CU),
+                'frac_of_occupied_cus': ach / (LDS_PEAK_GBS * min(1., sys_per_launch / N_CU)),
+                'fp64': {'achieved_tflops': flops_per_launch / (avg_ms * 1e-3) / 1e12, 'peak_tflops': FP64_PEAK_TF,
+                         'frac': flops_per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TF,
+                         'flops_model': '10 N^3 per solve (SURVEY 8d F2)'}}
+        # ---- second object: the fused evaluation kernel (0.5 % of the step, the headline kernel of the evaluate half)
+        out['roofline_eval'] = {
+            'kernel': 'k_eval_sph_fast<6,4,1> (+ k_hull_mask)', 'bound': 'fp64 VALU (AI ~94 flop/B >> 9.8)',
+            'kernel_ms_hull_on': ev_kernel_hull, 'kernel_ms_hull_off': ev_kernel_nohull, 'call_ms_hull_off': ev_call_nohull,
+            'call_ms_hull_on': ev,
+            'hbm': {'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': EVAL_BYTES_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'traffic': traffic_eval},
+            'valu': {'achieved': EVAL_FLOPS_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e12, 'peak': FP64_PEAK_TF,
+                     'unit': 'TFLOP/s', 'frac': EVAL_FLOPS_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e12 / FP64_PEAK_TF,
+                     'flops_model': '~3.0 kflop/point at the default order (SURVEY 8d E1)'},
+            'points_per_sec_hull_on': Q * T / (ev_kernel_hull * 1e-3), 'points_per_sec_hull_off': Q * T / (ev_kernel_nohull * 1e-3)}
         if many is not None:
             out['eval_many_timesteps'] = many
         if batched is not None:
             out['batched_records'] = batched
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(lat, lon, alt, value, error, R, args.grid)
-        elif world == 1:
-            out['cpu_baseline'] = None
+        if world == 1:
+            out['cpu_baseline'] = cpu
         real_stdout.write(json.dumps(out) + '\n')
         real_stdout.flush()
     comm.close()

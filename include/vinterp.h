@@ -140,9 +140,13 @@ int  vi_eval_kernel_ms(vi_ctx* ctx, double* ms);
 /* device time of the eigen-solve kernel launches (the kernel the fit spends its time in), from one HIP event pair
  * per launch on the context's stream.  enable = 1 starts / resets recording, 0 stops it, -1 only reads; the
  * outputs (each may be NULL) describe the period since the last reset: launches, systems solved, number of
- * launches whose duration is included (the 128 most recent at most), their summed and maximal duration (ms). */
+ * launches whose duration is included (the 2048 most recent at most), their summed and maximal duration (ms). */
 int  vi_solve_timing(vi_ctx* ctx, int enable, int64_t* launches, int64_t* systems, int64_t* timed,
                      double* total_ms, double* max_ms);
+/* Jacobi rounds (one round = one pass of the LDS-resident matrix through the registers) summed over the systems of
+ * all launches since vi_solve_timing(enable = 1); read it BEFORE the next vi_solve_timing call with enable >= 0,
+ * which resets it.  The unit the LDS roofline of the eigen-solve kernel is priced in (bench.py). */
+int  vi_solve_rounds(vi_ctx* ctx, int64_t* rounds);
 /* host-pointer convenience form of the same call */
 int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const double* h_lon,
                       const double* h_alt, int64_t T, const double* h_C,

@@ -314,6 +314,69 @@ def gen_fit(workdir):
          self_noise=np.array([rel(it2.Coeffs[t], it.Coeffs[t]) for t in range(2)]))
 
 
+def gen_default_many(workdir):
+    """Default order (N = 144), where the reference does not reproduce itself: many fresh records, each fitted
+    by the reference three times - as is, and with 1e-14 relative noise on its basis (two seeds).  The spread of the three
+    runs is the yardstick the GPU parity test measures the build against (outcome class, log10 alpha, densities in the
+    hull).  'default16': 11 x 50 geometry, 16 records; 'default_c2': the 26 x 100 geometry of BASELINE configs[1],
+    4 records (record 0 is the record bench.py fits)."""
+    from volumetricinterp.estimate import Estimate
+    regs = np.load(os.path.join(GOLD, 'regmat.npz'))
+    R = regs['default_curvature']
+    cfg = config_text(reglist='curvature', maxk=4, maxl=6, cap=10)
+    m = ref_model(cfg)
+    g = synth.query_grid(8)
+    for tag, geom, T, seed0 in [('default16', synth.GEOM_C1, 16, 6000), ('default_c2', synth.GEOM_C2, 4, 1000)]:
+        lat, lon, alt = synth.beams(*geom, seed=0)
+        A = m.basis(lat, lon, alt)
+        value, error = synth.synth_records(A, T, seed0=seed0)
+        utime = synth.unix_times(T)
+        runs = []
+        for perturb in (None, 77, 78):
+            it, rec = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, {'curvature': R}, perturb=perturb)
+            alphas = np.array([rp['curvature'] for rp in rec.reg_params[:T]], dtype=np.float64)
+            es = Estimate.__new__(Estimate)
+            es.timetol, es.timeinterp = 60., False
+            es.Coeffs, es.Covariance, es.time, es.hull_vert = it.Coeffs, it.Covariance, utime, it.hull_vert
+            es.model = m
+            dens = []
+            for t in range(T):
+                if not np.all(np.isfinite(it.Coeffs[t])):
+                    dens.append(np.full(g[0].shape, np.nan))
+                    continue
+                t_mid = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(np.mean(utime[t])))
+                dens.append(es(t_mid, *g, check_hull=True))
+            # scale factor of each record's search: the nu of its last chi2objfunct calls / number of points
+            calls = np.array(rec.chi2_calls)
+            # nu = scale factor x number of points of each record's LAST chi2objfunct call (the scale factor that
+            # bracketed, or 1.0 x npts when none did); records start at (alpha = 0, nu = 0.6 npts)
+            npts = np.isfinite(value).sum(axis=1)
+            nu_last, tt = [], -1
+            for a_, nu_, _v in calls:
+                if a_ == 0.0 and tt + 1 < T and abs(nu_ - 0.6 * npts[tt + 1]) < 1e-9 and (tt < 0 or ncall > 0):
+                    tt += 1
+                    nu_last.append(nu_)
+                    ncall = 0
+                nu_last[tt] = nu_
+                ncall += 1
+            runs.append(dict(alpha=alphas, Coeffs=it.Coeffs, chi_sq=it.chi_sq, dens=np.array(dens), calls=calls,
+                             hull_vert=it.hull_vert, evalC=rec.evalC_calls, nu=np.array(nu_last)))
+            print(tag, 'perturb', perturb, 'log10 alpha', np.round(np.log10(np.where(alphas > 0, alphas, np.nan)), 4))
+        out = dict(cfg=np.array(cfg), reg=np.array('curvature'), R=R, lat=lat, lon=lon, alt=alt, utime=utime,
+                   value=value, error=error, hull_vert=runs[0]['hull_vert'], seed0=np.array(seed0),
+                   evalC_calls=np.array(runs[0]['evalC']), chi2_calls=runs[0]['calls'])
+        for k, r in enumerate(runs):
+            sfx = '' if k == 0 else '_p%d' % k
+            out['alpha' + sfx], out['Coeffs' + sfx], out['chi_sq' + sfx], out['dens' + sfx], out['nu' + sfx] = \
+                r['alpha'], r['Coeffs'], r['chi_sq'], r['dens'], r['nu']
+        if tag == 'default_c2':
+            W0 = error[0]**-2
+            out['rec0_AWA'] = np.einsum('ji,j,jk->ik', A, W0, A)
+            out['rec0_y'] = np.einsum('ji,j,j->i', A, W0, value[0])
+            out['rec0_A_head'] = A[:64]
+        save('fit_' + tag, **out)
+
+
 def gen_grad(workdir):
     """grad_basis (sphharmlag.py:148-184): advertised by the reference, never called by its own workflow."""
     out = {}
@@ -416,7 +479,8 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     setup_reference(args.ref)
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
-    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval)]
+    steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval),
+             ('default_many', gen_default_many)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue

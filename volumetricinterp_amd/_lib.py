@@ -81,12 +81,13 @@ _sig('vi_eval_f64_host', C.c_int, VOIDP, I64, c_double_p, c_double_p, c_double_p
 _sig('vi_eval_kernel_ms', C.c_int, VOIDP, c_double_p)
 _sig('vi_solve_timing', C.c_int, VOIDP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
      c_double_p, c_double_p)
+_sig('vi_solve_rounds', C.c_int, VOIDP, C.POINTER(C.c_int64))
 _sig('vi_rccl_unique_id', C.c_int, C.c_char_p)
 _sig('vi_rccl_init', C.c_int, VOIDP, C.c_int, C.c_int, C.c_char_p)
 _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
-EXPORTS = ['vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
+EXPORTS = ['vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
            'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']
@@ -127,11 +128,13 @@ class Context:
 
     def solve_timing(self, enable=-1):
         """Eigen-solve kernel timing (vi_solve_timing): returns a dict for the period since the last reset."""
-        n, sy, tm = C.c_int64(), C.c_int64(), C.c_int64()
+        n, sy, tm, rd = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         tot, mx = C.c_double(), C.c_double()
+        check(lib.vi_solve_rounds(self.handle, C.byref(rd)), 'vi_solve_rounds')      # before the reset below
         check(lib.vi_solve_timing(self.handle, int(enable), C.byref(n), C.byref(sy), C.byref(tm), C.byref(tot),
                                   C.byref(mx)), 'vi_solve_timing')
-        return dict(launches=n.value, systems=sy.value, timed=tm.value, total_ms=tot.value, max_ms=mx.value)
+        return dict(launches=n.value, systems=sy.value, timed=tm.value, total_ms=tot.value, max_ms=mx.value,
+                    rounds=rd.value)
 
     def empty(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)

@@ -71,6 +71,7 @@ extern "C" void vi_ctx_destroy(vi_ctx* c)
     for (int i = 0; i < vi_ctx::NSOLVE_EV; ++i)
         for (int j = 0; j < 2; ++j)
             if (c->evs[i][j]) (void)hipEventDestroy(c->evs[i][j]);
+    if (c->d_rounds) (void)hipFree(c->d_rounds);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -221,10 +222,27 @@ extern "C" int vi_solve_timing(vi_ctx* c, int enable, int64_t* launches, int64_t
         if (enable && !c->evs[0][0])
             for (int i = 0; i < vi_ctx::NSOLVE_EV; ++i)
                 for (int j = 0; j < 2; ++j) VI_HIP(hipEventCreate(&c->evs[i][j]));
+        if (enable && !c->d_rounds) VI_HIP(hipMalloc((void**)&c->d_rounds, sizeof(unsigned long long)));
+        if (c->d_rounds) VI_HIP(hipMemsetAsync(c->d_rounds, 0, sizeof(unsigned long long), c->stream));
         c->solve_timing = enable != 0;
         c->solve_launches = 0;
         c->solve_systems = 0;
     }
+    return VI_OK;
+}
+
+// Jacobi rounds (one round = one pass of the whole LDS-resident matrix through the registers) summed over all systems
+// of the launches recorded since vi_solve_timing(enable = 1): the unit the LDS roofline of the kernel is priced in.
+extern "C" int vi_solve_rounds(vi_ctx* c, int64_t* rounds)
+{
+    VI_REQUIRE(c && rounds, "null argument");
+    *rounds = 0;
+    if (!c->d_rounds) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    VI_HIP(hipStreamSynchronize(c->stream));
+    unsigned long long h = 0;
+    VI_HIP(hipMemcpy(&h, c->d_rounds, sizeof(h), hipMemcpyDeviceToHost));
+    *rounds = (int64_t)h;
     return VI_OK;
 }
 

@@ -51,11 +51,12 @@ struct vi_ctx {
     int n_cu = 256;
     void* rccl_comm = nullptr;   // ncclComm_t, created by vi_rccl_init
     // opt-in timing of the eigen-solve kernel launches (vi_solve_timing): ring of HIP event pairs on the stream
-    static constexpr int NSOLVE_EV = 128;
+    static constexpr int NSOLVE_EV = 2048;
     bool solve_timing = false;
     hipEvent_t evs[NSOLVE_EV][2] = {};
     long long solve_launches = 0;      // launches recorded since the last reset
     long long solve_systems = 0;       // systems in those launches
+    unsigned long long* d_rounds = nullptr;   // device counter: Jacobi rounds (LDS passes) of the recorded launches
 };
 
 int vi_ctx_workspace(vi_ctx* ctx, size_t bytes, void** out);

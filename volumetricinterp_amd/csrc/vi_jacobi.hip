@@ -159,7 +159,8 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
                                                       double2* __restrict__ rotlog, int64_t log_stride,
                                                       int max_sweeps, int* __restrict__ sweeps_out,
                                                       double* __restrict__ lam_out, int lam_raw,
-                                                      int* __restrict__ nround_out)
+                                                      int* __restrict__ nround_out,
+                                                      unsigned long long* __restrict__ round_acc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int Np = (N + 1) & ~1;          // padded to even with an inert index
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(JBS) void k_jacobi_solve(int N, const double* __res
         if (rank) rank[sys] = (int)tot;
         if (sweeps_out) sweeps_out[sys] = sweep;
         if (nround_out) nround_out[sys] = (int)nround;
+        if (round_acc) atomicAdd(round_acc, (unsigned long long)nround);      // bench only (vi_solve_timing)
     }
     VI_STAMP(5);
     // ---- C = V g : undo (permutation, rotation) round by round ----------------------------------------------
@@ -622,7 +624,8 @@ static int launch_jacobi(vi_ctx* c, int64_t B, int N, const double* d_X, const d
     const int slot = (int)(c->solve_launches % vi_ctx::NSOLVE_EV);
     if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[slot][0], c->stream));
     hipLaunchKernelGGL(k_jacobi_solve<IT>, dim3((unsigned)B), dim3(JBS), shm, c->stream, N, d_X, d_scl, d_y, d_rec,
-                       rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround);
+                       rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround,
+                       c->solve_timing ? c->d_rounds : nullptr);
     VI_HIP(hipGetLastError());
     if (c->solve_timing) {
         VI_HIP(hipEventRecord(c->evs[slot][1], c->stream));

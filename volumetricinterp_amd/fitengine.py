@@ -223,7 +223,9 @@ class FitEngine(object):
             import time
             t_tr = time.perf_counter()
         is_int = log10a == np.floor(log10a)
-        if B == 1 and not is_int[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot:
+        force = getattr(self, '_force_cold', None)
+        forced = (np.array([int(r) in force for r in rec.tolist()], dtype=bool) if force else np.zeros(B, dtype=bool))
+        if B == 1 and not is_int[0] and not forced[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot:
             # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
             scratch = self._buf('w_one', (N + 8,))
@@ -244,13 +246,14 @@ class FitEngine(object):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
-        walkwarm = is_int & (log10a <= self.WALK_WARM_BELOW) if self.walk_warm_enabled() else np.zeros(B, dtype=bool)
+        walkwarm = (is_int & (log10a <= self.WALK_WARM_BELOW) & ~forced if self.walk_warm_enabled()
+                    else np.zeros(B, dtype=bool))
         # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
         # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
         warm = np.zeros(B, dtype=bool)
         prep = np.zeros(B, dtype=bool)
         by_rec = {}
-        for j in np.nonzero(~is_int)[0].tolist():
+        for j in np.nonzero(~is_int & ~forced)[0].tolist():
             by_rec.setdefault(int(rec[j]), []).append(j)
         for r, js in by_rec.items():
             if r in self._warm_slot:
@@ -259,7 +262,7 @@ class FitEngine(object):
                 jm = js[len(js) // 2]
                 prep[jm] = True
                 warm[[j for j in js if j != jm]] = True
-        cold = is_int & (~walkwarm)
+        cold = (is_int & (~walkwarm)) | forced           # forced: records whose search is being redone cold
         order = np.concatenate([np.nonzero(cold)[0], np.nonzero(walkwarm)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
         nc, nww, npre, nw = int(cold.sum()), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
         h = self.ctx.handle
@@ -338,16 +341,25 @@ class FitEngine(object):
             return int(max(15, min(255, 256 // max(1, self.T) - 1)))
         return 0
 
-    def search(self, npts, prefetch=None, multisection=None):
+    def search(self, npts, prefetch=None, multisection=None, only=None, cold=False):
         """find_reg_param with method 'chi2' for every loaded record (interpolate.py:97-147).
 
         npts[t] = number of finite points of record t, or None to skip it.  Returns a list of
-        {name: alpha} dicts (NaN where the search fails) and per-name search info."""
+        {name: alpha} dicts (NaN where the search fails) and per-name search info.
+        only: restrict to these records (the others are reported as skipped); cold: serve every chi^2 request of
+        the search from cold solves of the untransformed system (no rotated-system warm start) - the path the
+        consistency guard of fit_resident() falls back to."""
         T = self.T
         if prefetch is None:
             prefetch = self.default_prefetch()
         if multisection is None:
             multisection = self.default_multisection()
+        if only is not None:
+            only = set(int(t) for t in only)
+            npts = [n if t in only else None for t, n in enumerate(npts)]
+        self._force_cold = set(range(T)) if (cold and only is None) else (set(only) if cold else set())
+        if cold:
+            multisection = 0                    # the reference's own iteration only
         params = [dict() for _ in range(T)]
         infos = {}
         for name in self.regularization_list:
@@ -360,6 +372,7 @@ class FitEngine(object):
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
+        self._force_cold = set()
         return params, infos
 
     # ---- generalised cross validation (interpolate.py:263-351) ------------------------------------------
@@ -405,16 +418,18 @@ class FitEngine(object):
             infos[name] = dict(outcomes=outcomes)
         return params, infos
 
-    def finalize(self, params, calccov=True):
+    def finalize(self, params, calccov=True, only=None):
         """Final eval_C(calccov=True) + chi^2 for every record (interpolate.py:566-569).
 
-        Records whose parameters contain NaN become NaN rows (interpolate.py:558-563)."""
+        Records whose parameters contain NaN become NaN rows (interpolate.py:558-563); with `only`, so do the
+        records not listed."""
         T, N = self.T, self.N
         Coeffs = np.full((T, N), np.nan)
         Cov = np.full((T, N, N), np.nan) if calccov else None
         chi = np.full(T, np.nan)
         ranks = np.full(T, -1, dtype=np.int32)
-        good = [t for t in range(T) if not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
+        good = [t for t in range(T) if (only is None or t in only)
+                and not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
         step = max(1, min(len(good), 2048))
         for s in range(0, len(good), step):
             idx = np.asarray(good[s:s + step], dtype=np.int32)
@@ -446,11 +461,59 @@ class FitEngine(object):
                 Cov[idx] = Db
         return Coeffs, Cov, chi, ranks
 
+    CONSISTENCY_TOL = 1e-6        # |chi^2_final - nu| <= tol * nu, else the record's root search is redone cold
+
+    def _search_and_finalize(self, npts, calccov, prefetch, multisection):
+        """chi^2 search + final solve, with a consistency guard between the two.
+
+        The root finder's iterates are served from each record's rotated system (warm start), the final
+        coefficients from a cold solve of the untransformed system.  Where X(alpha) has eigenvalues at the
+        truncation threshold the two can disagree about which of them survive (measured at the default order,
+        N = 144: chi^2 jumps by ~3 across such a point), and the alpha the warm search returns is then not a root of
+        the function the final solve evaluates.  So after the final solve, every 'root' record must satisfy
+        |chi^2_final - nu| <= 1e-6 nu; a record that does not has its search redone with cold solves only and is
+        finalised again.  If it still violates, chi^2(alpha) - nu has no root there but a sign-changing jump, which
+        is what Brent converges to in the reference as well (its golden records show final chi^2 of 540.9 and 526.2
+        for nu = 550); the record keeps the cold result and is flagged in its search info ('consistent': False)."""
+        params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
+        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        if len(self.regularization_list) != 1 or os.environ.get('VINTERP_GUARD', '1') == '0':
+            return params, infos, Coeffs, Cov, chi, ranks
+        name = self.regularization_list[0]
+        inf = infos[name]
+
+        def violators():
+            bad = []
+            for t in range(self.T):
+                if inf['outcomes'][t] != 'root':
+                    continue
+                nu = inf['info'][t]['sf'] * npts[t]
+                inf['info'][t]['chi2_minus_nu'] = float(chi[t] - nu)
+                inf['info'][t]['consistent'] = bool(abs(chi[t] - nu) <= self.CONSISTENCY_TOL * nu)
+                if not inf['info'][t]['consistent']:
+                    bad.append(t)
+            return bad
+        bad = violators()
+        inf['redone_cold'] = list(bad)
+        if bad and self.warm_enabled():
+            p2, i2 = self.search(npts, prefetch=prefetch, only=bad, cold=True)
+            C2, V2, c2, r2 = self.finalize(p2, calccov=calccov, only=set(bad))
+            for t in bad:
+                params[t] = p2[t]
+                inf['outcomes'][t] = i2[name]['outcomes'][t]
+                inf['info'][t] = i2[name]['info'][t]
+                inf['info'][t]['redone_cold'] = True
+                Coeffs[t], chi[t], ranks[t] = C2[t], c2[t], r2[t]
+                if calccov:
+                    Cov[t] = V2[t]
+            inf['evaluations'] += i2[name]['evaluations']
+            violators()
+        return params, infos, Coeffs, Cov, chi, ranks
+
     def fit_resident(self, npts, calccov=True, prefetch=None, multisection=None):
         """Fit the records made resident by upload_records()."""
         self.form_normal_equations()
-        params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
-        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
     def fit(self, W, b, npts, calccov=True, prefetch=None, multisection=None, method='chi2', point_lists=None):
@@ -459,8 +522,7 @@ class FitEngine(object):
             params, infos = self.search_gcv(point_lists)
             Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
             return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
-        params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
-        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
     def close(self):
