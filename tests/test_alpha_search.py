@@ -42,14 +42,14 @@ def test_brentq_restatement_matches_scipy_call_for_call(case):
         calls.append(x)
         return f(x)
     ref, info = scipy.optimize.brentq(logged, a, b, full_output=True, disp=True)
-    (root, iters, funcalls), xs = drive(AS.brentq_gen(a, b), f)
+    (root, iters, funcalls, _oe), xs = drive(AS.brentq_gen(a, b), f)
     assert root == ref                      # bit-identical iterate sequence
     assert xs == calls
     assert funcalls == info.function_calls
     if info.function_calls > 2:             # SciPy leaves `iterations` uninitialised when an end point is the root
         assert iters == info.iterations
     # supplying the known end values skips exactly the two initial evaluations
-    (root2, _, _), xs2 = drive(AS.brentq_gen(a, b, fa=f(a), fb=f(b)), f)
+    (root2, _, _, _), xs2 = drive(AS.brentq_gen(a, b, fa=f(a), fb=f(b)), f)
     assert root2 == ref and xs2 == calls[2:]
 
 

@@ -1,22 +1,51 @@
-"""Diagnostic (STAMPS=1 build): where a Jacobi round spends its cycles (wave 0 of workgroup 0)."""
-import ctypes as C, os, sys, numpy as np
+"""Diagnostic (GPU, stamped build tools/microbench/libvinterp_stamps.so = make with -DVI_STAMPS): where a Jacobi round
+spends its cycles.  Segments, per wave 0 (which computes the rotations) and the last wave (which only updates blocks):
+0 phase 1 (rotations), 1 block fetch issue, 2 wait at barrier 1, 3 rotation reads + update + stores, 4 wait at barrier 2,
+7 loop overhead.  Shares only - the stamped build itself runs slower than the product kernel."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from volumetricinterp_amd import _lib, fitengine
-ctx = _lib.get_context()
+lib = C.CDLL(os.path.join(ROOT, 'tools', 'microbench', 'libvinterp_stamps.so'), mode=C.RTLD_GLOBAL)
+VP, I64 = C.c_void_p, C.c_int64
+lib.vi_ctx_create.argtypes = [C.c_int, C.POINTER(VP)]
+lib.vi_dmalloc.argtypes = [VP, C.c_size_t, C.POINTER(VP)]
+lib.vi_h2d.argtypes = [VP, VP, VP, C.c_size_t]
+lib.vi_d2h.argtypes = [VP, VP, VP, C.c_size_t]
+lib.vi_eigvals_f64.argtypes = [VP, I64, C.c_int32, VP, VP, VP]
+lib.vi_ctx_sync.argtypes = [VP]
+ctx = VP()
+assert lib.vi_ctx_create(0, C.byref(ctx)) == 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 144
 rng = np.random.default_rng(0)
-N = 144
-A = rng.standard_normal((400, N)); M = A.T @ A
-X = np.stack([M + np.eye(N)])
-dX = ctx.to_device(X); dl = ctx.empty((1, N)); ds = ctx.empty((1,), np.int32)
-out = (C.c_double * 8)()
-_lib.lib.vi_debug_jacobi_stamps(out, 1)
-_lib.check(_lib.lib.vi_eigvals_f64(ctx.handle, 1, N, dX.ptr, dl.ptr, ds.ptr), 'eig'); ctx.sync()
-_lib.lib.vi_debug_jacobi_stamps(out, 1)
-sw = int(ds.download()[0]); rounds = sw * (N - 1)
-names = ['phase1 (rotation set-up)', 'phase2a block fetch', 'barrier 1 wait', 'phase2b update+store', 'barrier 2 wait',
-         'truncate/reduce', 'replay (all rounds)', 'loop overhead']
-print('sweeps', sw, 'rounds', rounds)
-tot = sum(out)
-for n, v in zip(names, out):
-    print('%-28s %10.0f ticks  %6.1f per round  %5.1f%%' % (n, v, v / rounds, 100 * v / tot))
+Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+X = (Q * rng.uniform(0.1, 1., N)) @ Q.T
+X = np.ascontiguousarray(0.5 * (X + X.T))[None]
+
+
+def dmalloc(n):
+    p = VP()
+    assert lib.vi_dmalloc(ctx, n, C.byref(p)) == 0
+    return p
+
+
+dX, dl, ds = dmalloc(X.nbytes), dmalloc(N * 8), dmalloc(4)
+out = (C.c_double * 16)()
+lib.vi_debug_jacobi_stamps(out, 1)
+lib.vi_h2d(ctx, dX, X.ctypes.data_as(VP), X.nbytes)
+assert lib.vi_eigvals_f64(ctx, 1, N, dX, dl, ds) == 0
+lib.vi_ctx_sync(ctx)
+sw = np.zeros(1, dtype=np.int32)
+lib.vi_d2h(ctx, sw.ctypes.data_as(VP), ds, 4)
+lib.vi_debug_jacobi_stamps(out, 0)
+v = np.array(list(out))
+Np = (N + 3) & ~3
+rounds = sw[0] * Np // 2
+names = ['diag stores + next rotations', 'fetch issue', 'wait barrier 1', 'update+stores', 'wait barrier 2', '-', '-', 'loop']
+print('N %d sweeps %d rounds %d' % (N, sw[0], rounds))
+for w, off in (('wave 0', 0), ('last wave', 8)):
+    tot = v[off:off + 8].sum()
+    print(w, 'cycles per round %.0f:' % (tot / rounds), '  '.join('%s %.0f' % (names[k], v[off + k] / rounds) for k in (0, 1, 2, 3, 4, 7)))

@@ -29,7 +29,7 @@ def slot_next(s, m):            # Brent-Luk on 2m slots, slot 0 fixed
 
 def rot_params(app, aqq, apq, drop, floor):
     aa = abs(apq)
-    tiny = max(abs(app), abs(aqq), aa) < drop
+    tiny = max(abs(app), abs(aqq), aa) < 0.0625 * drop
     if aa * aa > EPS * EPS * abs(app * aqq) and aa > floor and not tiny:
         d = aqq - app
         t = np.copysign(2.0 * apq, d * apq) / (abs(d) + np.sqrt(d * d + 4.0 * apq * apq))
@@ -52,7 +52,7 @@ def converged(A, drop, floor):
     d = np.abs(np.diag(A))
     off = np.abs(A - np.diag(np.diag(A)))
     big = np.maximum(np.maximum(d[:, None], d[None, :]), off)
-    viol = (off * off > EPS * EPS * np.abs(np.outer(np.diag(A), np.diag(A)))) & (off > floor) & ~(big < drop)
+    viol = (off * off > EPS * EPS * np.abs(np.outer(np.diag(A), np.diag(A)))) & (off > floor) & ~(big < 0.0625 * drop)
     return not viol.any()
 
 

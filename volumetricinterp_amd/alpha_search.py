@@ -33,7 +33,8 @@ def _signbit(x):
 
 
 def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
-    """Coroutine form of brentq: yields x, receives f(x); returns (root, iterations, funcalls).
+    """Coroutine form of brentq: yields x, receives f(x); returns (root, iterations, funcalls, other_end) with other_end
+    the far end of the final bracket (None when an end point is an exact zero).
 
     fa / fb may be supplied when already known (the function is deterministic)."""
     xpre, xcur = xa, xb
@@ -47,9 +48,9 @@ def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
         funcalls += 1
     fpre, fcur = fa, fb
     if fpre == 0:
-        return xpre, 0, funcalls
+        return xpre, 0, funcalls, None
     if fcur == 0:
-        return xcur, 0, funcalls
+        return xcur, 0, funcalls, None
     if _signbit(fpre) == _signbit(fcur):
         raise ValueError('f(a) and f(b) must have different signs')
     for it in range(1, maxiter + 1):
@@ -62,7 +63,7 @@ def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
         delta = (xtol + rtol * abs(xcur)) / 2
         sbis = (xblk - xcur) / 2
         if fcur == 0 or abs(sbis) < delta:
-            return xcur, it, funcalls
+            return xcur, it, funcalls, xblk
         if abs(spre) > delta and abs(fcur) < abs(fpre):
             if xpre == xblk:
                 stry = -fcur * (xcur - xpre) / (fcur - fpre)                      # secant
@@ -167,6 +168,7 @@ def chi2_search_gen(npts, multisection=0):
     if not bracket:
         return 'no_root', float('nan'), dict(sf=None)
     found = None
+    other_end = None
     if multisection:
         ms = multisection_gen(alpha, alpha0, val, val0, int(multisection))
         try:
@@ -186,10 +188,10 @@ def chi2_search_gen(npts, multisection=0):
             while True:
                 x = br.send((yield from f_at(x)) - nu)
         except StopIteration as stop:
-            root, iters, _ = stop.value
+            root, iters, _, other_end = stop.value
         finder = 'brentq'
     return 'root', float(np.power(10., root)), dict(sf=sf_used, bracket=(alpha, alpha0), log10_alpha=root,
-                                                     iterations=iters, finder=finder)
+                                                     iterations=iters, finder=finder, other_end=other_end)
 
 
 def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
@@ -257,3 +259,27 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
         for i, a, v in zip(rec, alp, vals):
             cache[i][a] = float(v)
     return ([r[1] for r in results], [r[0] for r in results], [r[2] for r in results], nevals)
+
+
+def run_brent_batched(brackets, f_batch):
+    """Brent's iteration on given brackets, batched over records: brackets = {rec: (xa, xb, fa, fb)} with f values
+    (chi^2 - nu) of opposite sign; f_batch(rec array, x array) -> f array.  Returns {rec: (root, iterations, other_end)}."""
+    gens, pending, out = {}, {}, {}
+    for i, (xa, xb, fa, fb) in brackets.items():
+        g = brentq_gen(xa, xb, fa=fa, fb=fb)
+        try:
+            pending[i] = next(g)
+            gens[i] = g
+        except StopIteration as stop:
+            out[i] = (stop.value[0], stop.value[1], stop.value[3])
+    while gens:
+        rec = np.array(sorted(gens), dtype=np.int32)
+        xs = np.array([pending[int(i)] for i in rec], dtype=np.float64)
+        vals = f_batch(rec, xs)
+        for i, v in zip(rec.tolist(), vals):
+            try:
+                pending[i] = gens[i].send(float(v))
+            except StopIteration as stop:
+                out[i] = (stop.value[0], stop.value[1], stop.value[3])
+                del gens[i], pending[i]
+    return out

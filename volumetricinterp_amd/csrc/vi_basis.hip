@@ -285,10 +285,14 @@ struct EvalSink {
 // `hull` is the internal buffer built by k_prep_hull: [c0 (3 doubles, 1 pad)] [F x 4 fp64 facet equations]
 // [F x float4 facets relative to c0].  With ~460 facets an fp64 test inside the evaluation kernel cost twice the
 // whole basis (dependent scalar loads), so the test is its own pass: the fp32 facets are staged in LDS once per
-// workgroup and evaluated relative to a reference point on the hull (fp32 error < 0.5 m for a hull of
-// ~1000 km); only lanes within HULL_BAND metres of the surface repeat the test in fp64.  The byte mask is
-// reused by every timestep tile of the evaluation.
+// workgroup and evaluated relative to a reference point c0 on the plane of facet 0; only lanes within a band of the
+// surface repeat the test in fp64.  The band covers the fp32 error of the prefilter: the float casts of normal and
+// offset plus three FMA roundings are a few units of 2^-24 |x - c0|, and c0 - the foot of the origin's perpendicular
+// on a facet plane - may lie far from the hull when that plane passes near the Earth's centre, so the band grows with
+// the distance: HULL_BAND + HULL_BAND_REL |x - c0| (4 m at the reference point, ~10 m at 6000 km).  Points with
+// non-finite coordinates are outside.  The byte mask is reused by every timestep tile of the evaluation.
 constexpr float HULL_BAND = 4.0f;
+constexpr float HULL_BAND_REL = 1.0e-6f;
 
 constexpr int HULL_PP = 4;          // points per thread: every facet read from LDS serves four points
 
@@ -314,7 +318,10 @@ __global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __
         dz[u] = (float)(Z[u] - hull[2]);
         dmax[u] = -3.0e38f;
     }
-    const float out_thr = (float)tol + HULL_BAND;
+    float band[HULL_PP];
+#pragma unroll
+    for (int u = 0; u < HULL_PP; ++u)
+        band[u] = HULL_BAND + HULL_BAND_REL * sqrtf(dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
     // two points per packed fp32 FMA (v_pk_fma_f32): the pass is VALU-bound (~2/3 of the scalar fp32 issue rate before)
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 px[HULL_PP / 2], py[HULL_PP / 2], pz[HULL_PP / 2];
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __
         // a point is outside as soon as ONE facet says so: leave when every point of the wave is decided
         bool done = true;
 #pragma unroll
-        for (int u = 0; u < HULL_PP; ++u) done = done && dmax[u] > out_thr;
+        for (int u = 0; u < HULL_PP; ++u) done = done && dmax[u] > (float)tol + band[u];
         if (__all(done)) break;
     }
     if (f + 8 > F)
@@ -349,8 +356,9 @@ __global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __
 #pragma unroll
     for (int u = 0; u < HULL_PP; ++u) {
         bool in;
-        if (dmax[u] > out_thr) in = false;
-        else if (dmax[u] < (float)tol - HULL_BAND) in = true;
+        if (!(fabsf(dx[u]) + fabsf(dy[u]) + fabsf(dz[u]) < 3.0e38f)) in = false;      // NaN / inf coordinates
+        else if (dmax[u] > (float)tol + band[u]) in = false;
+        else if (dmax[u] < (float)tol - band[u]) in = true;
         else {                                                           // borderline: exact fp64 test
             const double* __restrict__ eq = hull + 4;
             in = true;

@@ -323,8 +323,32 @@ int eig_method()
     return m;
 }
 
-constexpr int JACOBI_MAX_SWEEPS = 24;
-constexpr double JACOBI_FLOOR_COLD = 1e-22, JACOBI_FLOOR_WARM = 1e-16;
+// sweep cap of the in-LDS Jacobi solver (the rotation-log workspace is sized by it); VINTERP_MAX_SWEEPS overrides it
+int jacobi_max_sweeps()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VINTERP_MAX_SWEEPS");
+        v = e ? atoi(e) : 24;
+        if (v < 4) v = 4;
+        if (v > 200) v = 200;
+    }
+    return v;
+}
+#define JACOBI_MAX_SWEEPS jacobi_max_sweeps()
+constexpr double JACOBI_FLOOR_COLD = 1e-22;
+// absolute rotation floor of the warm (rotated-system) solves, relative to the scaled matrix; VINTERP_WARM_FLOOR overrides
+double jacobi_floor_warm()
+{
+    static double v = -1.0;
+    if (v < 0.0) {
+        const char* e = getenv("VINTERP_WARM_FLOOR");
+        v = e ? atof(e) : 1e-16;
+        if (!(v > 0.0)) v = 1e-16;
+    }
+    return v;
+}
+#define JACOBI_FLOOR_WARM jacobi_floor_warm()
 
 }  // namespace
 

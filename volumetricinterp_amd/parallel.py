@@ -17,9 +17,10 @@ Two transports:
   in one process crash (observed: SIGSEGV when torch was imported after libvinterp.so).
 * ``backend='gloo'`` (CPU tests): ``torch.distributed`` with the gloo backend.
 """
+import json
 import os
-import pickle
 import socket
+import stat
 import struct
 import time
 
@@ -58,6 +59,57 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+# Wire format of the control plane: length-prefixed frames of raw bytes; a list of frames is a count followed by the
+# frames; arrays travel as a JSON header (shape) + their float64 bytes.  Nothing received is ever unpickled.
+def _pack_parts(parts):
+    return struct.pack('<I', len(parts)) + b''.join(struct.pack('<Q', len(p)) + p for p in parts)
+
+
+def _unpack_parts(blob):
+    (n,) = struct.unpack_from('<I', blob, 0)
+    o, out = 4, []
+    for _ in range(n):
+        (k,) = struct.unpack_from('<Q', blob, o)
+        out.append(bytes(blob[o + 8:o + 8 + k]))
+        o += 8 + k
+    return out
+
+
+def _pack_array(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    head = json.dumps(list(a.shape)).encode('ascii')
+    return struct.pack('<I', len(head)) + head + a.tobytes()
+
+
+def _unpack_array(blob):
+    (k,) = struct.unpack_from('<I', blob, 0)
+    shape = tuple(int(x) for x in json.loads(blob[4:4 + k].decode('ascii')))
+    return np.frombuffer(blob, dtype=np.float64, offset=4 + k).reshape(shape).copy()
+
+
+def _private_socket_dir():
+    """A directory only this user can enter, for the rendezvous socket: $XDG_RUNTIME_DIR when set, else
+    /tmp/vinterp-<uid> created 0700.  A directory of that name that belongs to someone else, or that others may write
+    to, is refused (another local user could otherwise pre-create the socket path and impersonate rank 0)."""
+    base = os.environ.get('XDG_RUNTIME_DIR')
+    if base and os.path.isdir(base) and os.stat(base).st_uid == os.getuid():
+        return base
+    d = os.path.join('/tmp', 'vinterp-%d' % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError('%s is not a private directory of uid %d' % (d, os.getuid()))
+    return d
+
+
+def _peer_uid(conn):
+    cred = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize('3i'))
+    return struct.unpack('3i', cred)[1]
+
+
 class SocketGroup(object):
     """Star-shaped control plane of the ranks of one node: rank 0 serves a Unix-domain socket."""
 
@@ -65,8 +117,10 @@ class SocketGroup(object):
         self.rank, self.world = rank, world
         run = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
         port = os.environ.get('MASTER_PORT', '0')
-        self.path = os.environ.get('VINTERP_RDV_PATH', '/tmp/vinterp_rdv_%s_%s_%d.sock' % (port, run, os.getuid()))
+        self.path = os.environ.get('VINTERP_RDV_PATH') or os.path.join(_private_socket_dir(),
+                                                                       'rdv_%s_%s.sock' % (port, run))
         self.peers = {}
+        self.timeout = timeout
         if rank == 0:
             try:
                 os.unlink(self.path)
@@ -74,11 +128,15 @@ class SocketGroup(object):
                 pass
             srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
             srv.bind(self.path)
+            os.chmod(self.path, 0o600)
             srv.listen(world)
             srv.settimeout(timeout)
-            for _ in range(world - 1):
+            while len(self.peers) < world - 1:
                 conn, _ = srv.accept()
-                conn.settimeout(None)
+                if _peer_uid(conn) != os.getuid():          # not one of our ranks
+                    conn.close()
+                    continue
+                conn.settimeout(10 * timeout)               # finite: a dead rank must not hang the others for ever
                 (r,) = struct.unpack('<I', _recv_exact(conn, 4))
                 self.peers[r] = conn
             srv.close()
@@ -98,6 +156,10 @@ class SocketGroup(object):
                     if time.time() - t0 > timeout:
                         raise TimeoutError('rank %d could not reach rank 0 at %s' % (rank, self.path))
                     time.sleep(0.05)
+            if _peer_uid(s) != os.getuid():
+                s.close()
+                raise PermissionError('the process serving %s does not belong to uid %d' % (self.path, os.getuid()))
+            s.settimeout(10 * timeout)
             s.sendall(struct.pack('<I', rank))
             self.sock = s
 
@@ -107,12 +169,12 @@ class SocketGroup(object):
             parts = [payload] + [None] * (self.world - 1)
             for r, c in self.peers.items():
                 parts[r] = _recv_msg(c)
-            blob = pickle.dumps(parts)
+            blob = _pack_parts(parts)
             for c in self.peers.values():
                 _send_msg(c, blob)
             return parts
         _send_msg(self.sock, payload)
-        return pickle.loads(_recv_msg(self.sock))
+        return _unpack_parts(_recv_msg(self.sock))
 
     def bcast(self, payload):
         """Rank 0's bytes to everyone."""
@@ -216,7 +278,8 @@ class Comm(object):
             flat = t.numpy()
         else:
             meta = [(n, tuple(np.asarray(arrays[n]).shape)) for n in sorted(arrays)] if self.rank == 0 else None
-            meta = pickle.loads(self.grp.bcast(pickle.dumps(meta)))
+            meta = [(n, tuple(sh)) for n, sh in json.loads(self.grp.bcast(json.dumps(meta).encode('ascii') if self.rank == 0
+                                                                    else b'').decode('ascii'))]
             total = int(sum(int(np.prod(s, dtype=np.int64)) for _, s in meta))
             flat = (np.concatenate([np.asarray(arrays[n], dtype=np.float64).ravel() for n, _ in meta])
                     if self.rank == 0 and total else np.empty(total))
@@ -254,8 +317,8 @@ class Comm(object):
             outs = [torch.empty_like(t) for _ in range(self.world)]
             dist.all_gather(outs, t)
             return np.concatenate([o.numpy() for o in outs], axis=0)[:T]
-        parts = self.grp.allgather(pickle.dumps(local))
-        return np.concatenate([pickle.loads(p) for p in parts], axis=0)[:T]
+        parts = self.grp.allgather(_pack_array(local))
+        return np.concatenate([_unpack_array(p) for p in parts], axis=0)[:T]
 
     def barrier(self):
         if self.world <= 1:
