@@ -337,14 +337,18 @@ int jacobi_max_sweeps()
 }
 #define JACOBI_MAX_SWEEPS jacobi_max_sweeps()
 constexpr double JACOBI_FLOOR_COLD = 1e-22;
-// absolute rotation floor of the warm (rotated-system) solves, relative to the scaled matrix; VINTERP_WARM_FLOOR overrides
+// Absolute rotation floor of the warm (rotated-system) solves, relative to the scaled matrix (VINTERP_WARM_FLOOR overrides).
+// It was 1e-16 - about half the truncation cut eps * max|lambda| - so couplings of that size between eigenvalues next to
+// the cut were never rotated away, the warm and the cold solve disagreed about which of them survive, and at the default
+// order half of the records came back with a root of the warm chi^2 that the cold final solve missed by > 1e-4 nu
+// (measured, 1000 records 26 x 100: 464 searches redone with the floor at 1e-16, none at 1e-18, for 15 % more rounds)
 double jacobi_floor_warm()
 {
     static double v = -1.0;
     if (v < 0.0) {
         const char* e = getenv("VINTERP_WARM_FLOOR");
-        v = e ? atof(e) : 1e-16;
-        if (!(v > 0.0)) v = 1e-16;
+        v = e ? atof(e) : 1e-18;
+        if (!(v > 0.0)) v = 1e-18;
     }
     return v;
 }

