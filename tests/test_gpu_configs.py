@@ -1,0 +1,233 @@
+"""Every BASELINE.json configuration exercised on the GPU at its full size.
+
+configs[0] (11 x 50, default order, plumbing) and the evaluation leg of configs[1] (128^3) are covered by
+test_gpu_dropin.py / test_gpu_default_order.py / test_gpu_properties.py; this file adds
+  configs[1]  the FIT leg at 26 x 100, N = 144: normal equations, one solve, batch independence, chi^2 consistency;
+  configs[2]  1000 records of one geometry in one batch;
+  configs[3]  a 256^3 query grid shared by 64 timesteps (the matrix-core evaluation kernel);
+  configs[4]  the doubled order MAXK 8, MAXL 12 (N = 1152) on 64 x 200 points: basis, normal equations, one solve.
+Sizes the CPU oracle cannot reach in seconds are checked stage by stage against NumPy / SciPy on the same inputs and
+through size-independent properties (records are independent, the evaluation is linear in the coefficients)."""
+import io
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from conftest import load_golden, rel
+
+pytestmark = pytest.mark.gpu
+
+CFG144 = ('[DEFAULT]\nREGULARIZATION_LIST = curvature\nREGULARIZATION_METHOD = chi2\n'
+          '[MODEL]\nNAME = sphharmlag\nMAXK = 4\nMAXL = 6\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\nLONCP = 262\n')
+CFG1152 = ('[DEFAULT]\nREGULARIZATION_LIST = curvature\nREGULARIZATION_METHOD = chi2\n'
+           '[MODEL]\nNAME = sphharmlag\nMAXK = 8\nMAXL = 12\nCAP_LIM = 15\nMAX_Z_INT = INF\nLATCP = 78\nLONCP = 262\n')
+EPS = np.finfo(float).eps
+
+
+def _engine(cfg, geom, R=None):
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    from volumetricinterp_amd.models.sphharmlag import Model
+    m = Model(io.StringIO(cfg))
+    ctx = m.ctx
+    lat, lon, alt = synth.beams(*geom, seed=0)
+    P = lat.size
+    At = m.basis_device(ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(alt), P, transposed=True)
+    A = At.download().T
+    if R is None:
+        R = load_golden('regmat')['default_curvature']
+    eng = FitEngine(ctx, At, P, m.nbasis, {'curvature': R}, ['curvature'])
+    return m, ctx, eng, A, (lat, lon, alt)
+
+
+def _solve(ctx, X, y):
+    from volumetricinterp_amd import _lib
+    B, N = X.shape[0], X.shape[1]
+    dX, dy = ctx.to_device(X.copy()), ctx.to_device(y)
+    dC, drank = ctx.empty((B, N)), ctx.empty((B,), np.int32)
+    _lib.check(_lib.lib.vi_solve_trunc_f64(ctx.handle, B, N, dX.ptr, dy.ptr, None, EPS, dC.ptr, drank.ptr, N * EPS, None),
+               'vi_solve_trunc_f64')
+    return dC.download(), drank.download()
+
+
+# ---- configs[1]: fit leg, 26 x 100, N = 144 --------------------------------------------------------------------------
+def test_c1_normal_equations_and_one_solve():
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    f = load_golden('fit_default_c2')
+    W, b = f['error']**-2., f['value']
+    eng.load_records(W, b)
+    AWA, y = eng.normal_equations()
+    for t in range(W.shape[0]):
+        assert rel(AWA[t], (A.T * W[t]) @ A) <= 1e-13                      # L3: vs a NumPy GEMM on the same basis
+        assert rel(y[t], A.T @ (W[t] * b[t])) <= 1e-13
+    # the reference's own normal equations (its einsum on its scipy basis): the device basis is within 1e-11 per column
+    assert rel(AWA[0], f['rec0_AWA']) <= 1e-9 and rel(y[0], f['rec0_y']) <= 1e-9
+    # L4: one system where LAPACK is a yardstick - at alpha = 1e-12 the kept part of X = A^T W A + alpha R is well separated
+    # from the cut (the columns of A span 21 decades, so X is never of full numerical rank at this order)
+    X = AWA[0] + 1e-12 * f['R']
+    C, rank = _solve(ctx, X[None], y[:1])
+    sv = np.linalg.svd(X, compute_uv=False)
+    assert rank[0] == int((sv > EPS * sv[0]).sum())
+    Cl = scipy.linalg.lstsq(X, y[0])[0]
+    assert rel(A @ C[0], A @ Cl) <= 1e-6
+    assert abs(float(sum((A @ C[0] - b[0])**2 * W[0])) / float(sum((A @ Cl - b[0])**2 * W[0])) - 1.) <= 1e-6
+    # and at the reference's own alpha (rank-deficient, indefinite): chi^2 against LAPACK within LAPACK's own spread (its
+    # chi^2 is two-valued at the 1e-3 level under one ulp on alpha; exact arithmetic is in test_gpu_default_order.py)
+    Xr = AWA[0] + f['alpha'][0] * f['R']
+    Cr, _ = _solve(ctx, Xr[None], y[:1])
+    chi = lambda c: float(sum((A @ c - b[0])**2 * W[0]))
+    assert abs(chi(Cr[0]) - chi(scipy.linalg.lstsq(Xr, y[0])[0])) <= 5e-2 * chi(Cr[0])
+
+
+def test_c1_fit_is_independent_of_the_batch_and_consistent():
+    """Records are independent (interpolate.py:511): a record fitted alone, in a batch of 8 and in a batch of 40 (where
+    the far walk uses the alpha -> 0 eigenbasis) gets the same alpha and coefficients, at the benchmarked order."""
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P = A.shape[0]
+    value, error = synth.synth_records(A, 40, seed0=1000)
+    W = error**-2.
+    full = eng.fit(W, value, [P] * 40)
+    eight = eng.fit(W[:8], value[:8], [P] * 8)
+    info = full['search']['curvature']
+    nroot = 0
+    for t in (0, 3, 5):
+        one = eng.fit(W[t:t + 1], value[t:t + 1], [P])
+        for other in (eight, full):
+            a1, a2 = one['reg_params'][0]['curvature'], other['reg_params'][t]['curvature']
+            # Not bit for bit: rocBLAS picks different kernels for different batch counts (A^T W A and A c differ in the
+            # 16th digit), the batch of 40 serves the far walk (alpha <= 1e-31) from each record's alpha -> 0 eigenbasis,
+            # and at this order chi^2(alpha) has jumps at the 1e-6 scale (eigenvalues of X(alpha) crossing the cut), so
+            # Brent's last steps - and the root - agree to a few 1e-6 decades, not to its xtol of 2e-12.
+            tol = 2e-5
+            assert (np.isnan(a1) and np.isnan(a2)) or abs(math.log10(a1) - math.log10(a2)) <= tol, (t, a1, a2)
+            if not np.isnan(a1):
+                # same alpha to 1e-9, yet chi^2 may differ in the 6th digit: X(alpha) has eigenvalues at the cut
+                assert abs(one['chi_sq'][0] - other['chi_sq'][t]) <= 1e-5 * one['chi_sq'][0]
+                fit1, fit2 = A @ one['Coeffs'][0], A @ other['Coeffs'][t]
+                assert rel(fit1, fit2) <= 1e-4, t
+    for t in range(40):
+        if info['outcomes'][t] != 'root':
+            continue
+        nroot += 1
+        i_t = info['info'][t]
+        nu = i_t['sf'] * P
+        # chi^2-consistency: the final (cold) chi^2 meets the target the search declared, or the record is flagged
+        assert abs(full['chi_sq'][t] - nu) <= 1e-4 * nu or i_t.get('jump'), (t, full['chi_sq'][t], nu, i_t)
+    assert nroot >= 30
+
+
+# ---- configs[2]: 1000 records of one geometry ----------------------------------------------------------------------------
+def test_c2_thousand_records_one_batch():
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 1000
+    value, error = synth.synth_records(A, T, seed0=5000)
+    W = error**-2.
+    Wbad = W.copy()
+    Wbad[500, 7] = np.inf                                   # a record the reference turns into a NaN row (lstsq ValueError)
+    npts = [P] * T
+    npts_bad = list(npts)
+    npts_bad[500] = None
+    Wz = Wbad.copy()
+    Wz[500] = 0.
+    res = eng.fit(W, value, npts)
+    oc = res['search']['curvature']['outcomes']
+    good = np.array([o == 'root' or o == 'too_smooth' for o in oc])
+    assert good.sum() >= 800
+    assert np.all(np.isfinite(res['Coeffs'][good])) and np.all(np.isfinite(res['chi_sq'][good]))
+    assert np.all(np.isnan(res['Coeffs'][~good]))           # 'no_root' -> NaN rows (interpolate.py:558-563)
+    assert np.all(np.isfinite(res['Covariance'][good][:, 0, 0]))
+    # record alone == record in the batch
+    for t in (1, 499, 998):
+        one = eng.fit(W[t:t + 1], value[t:t + 1], [P])
+        a1, a2 = one['reg_params'][0]['curvature'], res['reg_params'][t]['curvature']
+        # (2e-5 decades: the batch serves the far walk from the alpha -> 0 eigenbasis, see the configs[1] test)
+        assert (np.isnan(a1) and np.isnan(a2)) or abs(math.log10(a1) - math.log10(a2)) <= 2e-5, (t, a1, a2)
+        if not np.isnan(a1):
+            assert rel(A @ one['Coeffs'][0], A @ res['Coeffs'][t]) <= 1e-4
+    # NaN-row isolation: a skipped record in the middle of the batch changes nothing for its neighbours
+    res2 = eng.fit(Wz, value, npts_bad)
+    assert np.all(np.isnan(res2['Coeffs'][500])) and np.isnan(res2['chi_sq'][500])
+    for t in (499, 501, 0, 999):
+        assert np.array_equal(res2['Coeffs'][t], res['Coeffs'][t], equal_nan=True)
+
+
+# ---- configs[3]: 256^3 grid shared by 64 timesteps (K2m) -------------------------------------------------------------------
+def test_c3_256cubed_64_timesteps_on_device():
+    from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.models.sphharmlag import Model
+    m = Model(io.StringIO(CFG144))
+    ctx = m.ctx
+    h = m.handle(ctx)
+    n, T, N = 256, 64, 144
+    Q = n**3
+    g = synth.query_grid(n)
+    dq = [ctx.to_device(np.ascontiguousarray(a.ravel())) for a in g]
+    rng = np.random.default_rng(7)
+    C = rng.standard_normal((T, N))
+    C[2] = 1.5 * C[0] - 0.25 * C[1]
+    dC = ctx.to_device(C)
+    dout = ctx.empty((T, Q))                                 # 8.6 GB, stays on the device
+
+    def rows(darr, t, lo, cnt):
+        out = np.empty(cnt)
+        _lib.check(_lib.lib.vi_d2h(ctx.handle, out.ctypes.data_as(_lib.VOIDP), darr.offset_ptr(t * Q + lo), out.nbytes), 'd2h')
+        return out
+    _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, T, dC.ptr, None, 0, 0., dout.ptr), 'vi_eval_f64')
+    S = 1 << 20
+    for lo in (0, Q // 2 - 12345, Q - S):
+        r0, r1, r2 = rows(dout, 0, lo, S), rows(dout, 1, lo, S), rows(dout, 2, lo, S)
+        assert np.all(np.isfinite(r0))
+        assert rel(r2, 1.5 * r0 - 0.25 * r1) <= 1e-12                   # linear in the coefficients
+    # tile agreement: row 63 evaluated alone (the one-timestep VALU kernel) against the same row out of the 64-tile
+    d1 = ctx.empty((1, Q))
+    _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, 1, dC.offset_ptr(63 * N), None, 0, 0., d1.ptr),
+               'vi_eval_f64')
+    a = np.empty(S)
+    _lib.check(_lib.lib.vi_d2h(ctx.handle, a.ctypes.data_as(_lib.VOIDP), d1.offset_ptr(Q - S), a.nbytes), 'd2h')
+    assert rel(a, rows(dout, 63, Q - S, S)) <= 1e-12
+    # chunked output: the second half of the grid evaluated on its own equals the second half of the whole
+    Qh = Q // 2
+    d2 = ctx.empty((T, Qh))
+    _lib.check(_lib.lib.vi_eval_f64(h, Qh, dq[0].offset_ptr(Qh), dq[1].offset_ptr(Qh), dq[2].offset_ptr(Qh), T, dC.ptr, None, 0,
+                                    0., d2.ptr), 'vi_eval_f64')
+    b = np.empty(S)
+    _lib.check(_lib.lib.vi_d2h(ctx.handle, b.ctypes.data_as(_lib.VOIDP), d2.offset_ptr(17 * Qh + 1000), b.nbytes), 'd2h')
+    assert np.array_equal(b, rows(dout, 17, Qh + 1000, S))
+    for x in (dout, d1, d2, dC, *dq):
+        x.free()
+
+
+# ---- configs[4]: doubled order, N = 1152, 64 x 200 points -------------------------------------------------------------------
+def test_c4_doubled_order_stages():
+    import oracle
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, (lat, lon, alt) = _engine(CFG1152, synth.GEOM_C5, R=np.eye(1152))
+    P, N = A.shape
+    assert (P, N) == (12800, 1152) and np.all(np.isfinite(A))
+    # basis against the oracle (scipy lpmv at non-integer degrees 12 l + 2.5) on a sample of the points
+    o = oracle.SphHarmLagOracle(maxk=8, maxl=12, cap_lim_deg=15.)
+    idx = np.linspace(0, P - 1, 48).astype(int)
+    Ao = o.basis(lat[idx], lon[idx], alt[idx])
+    scale = np.max(np.abs(Ao), axis=0)
+    assert np.max(np.max(np.abs(A[idx] - Ao), axis=0) / scale) <= 1e-10
+    # normal equations against a NumPy GEMM
+    value, error = synth.synth_records(A, 2, seed0=1000)
+    W = error**-2.
+    eng.load_records(W, value)
+    AWA, y = eng.normal_equations()
+    for t in range(2):
+        assert rel(AWA[t], (A.T * W[t]) @ A) <= 1e-13
+        assert rel(y[t], A.T @ (W[t] * value[t])) <= 1e-13
+    # one regularised solve against LAPACK: R = I * mean|diag| (synthetic at orders without a fixture), alpha = 1e-6
+    X = AWA[0] + 1e-6 * np.mean(np.abs(np.diag(AWA[0]))) * np.eye(N)
+    C, rank = _solve(ctx, X[None], y[:1])
+    ref = scipy.linalg.lstsq(X, y[0])[0]
+    assert rank[0] == N
+    assert rel(C[0], ref) <= 1e-7
+    fit = A @ C[0]
+    assert rel(fit, A @ ref) <= 1e-10

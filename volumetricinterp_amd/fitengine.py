@@ -14,6 +14,7 @@ Device-side engine behind ``Interpolate.calc_coeffs`` / ``eval_C`` /
   (``vi_form_system_f64`` -> ``vi_solve_trunc_f64`` -> ``vi_chi2_f64``).
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -212,9 +213,8 @@ class FitEngine(object):
 
         * integer log10(alpha) - the bracket walk - are solved cold, except (full launches only) the far tail
           alpha <= 1e-31, which is solved in the record's alpha -> 0 eigenbasis;
-        * the first non-integer request of a record (Brent's first iterate, or the middle sample of a
-          multisection round) is solved cold *with eigenvectors*, which sets up the record's rotated system;
-          all other root-finder requests use it."""
+        * root-finder requests (non-integer) are solved in the record's rotated system, which is set up (a cold
+          decomposition with eigenvectors) at the middle of the record's unit bracket when its first request arrives."""
         rec = np.ascontiguousarray(rec, dtype=np.int32)
         log10a = np.asarray(log10a, dtype=np.float64)
         B, N = len(rec), self.N
@@ -255,13 +255,24 @@ class FitEngine(object):
         by_rec = {}
         for j in np.nonzero(~is_int & ~forced)[0].tolist():
             by_rec.setdefault(int(rec[j]), []).append(j)
+        need = {}
         for r, js in by_rec.items():
-            if r in self._warm_slot:
-                warm[js] = True
-            else:
-                jm = js[len(js) // 2]
-                prep[jm] = True
-                warm[[j for j in js if j != jm]] = True
+            warm[js] = True
+            if r not in self._warm_slot:
+                # The rotated system of a record is set up at the MIDDLE of its unit bracket, 10^(floor(x) + 1/2),
+                # whatever the request that triggers it (Brent's first iterate, a multisection sample): the warm chi^2 is
+                # then one function of alpha per record, independent of the batch the record is fitted in and of the
+                # root finder's path - alone or among 999 others, a record sees the same values and Brent takes the
+                # same steps.  (It used to be set up at the first request; a record fitted alone, whose first request
+                # is a multisection sample, then got another basis, other rounding and sometimes another of the several
+                # roots of a default-order bracket than the same record inside a batch.)
+                need[r] = math.floor(float(log10a[js[0]])) + 0.5
+        if need:
+            recs_n = sorted(need)
+            scratchC = self._buf('wp_scratchC', (len(recs_n), N))
+            scratchR = self._buf('wp_scratchR', (len(recs_n),), np.int32)
+            self._warm_prepare('w_', self._warm_slot, recs_n, [float(np.power(10., need[r])) for r in recs_n], name,
+                               scratchC.ptr, scratchR.ptr)
         cold = (is_int & (~walkwarm)) | forced           # forced: records whose search is being redone cold
         order = np.concatenate([np.nonzero(cold)[0], np.nonzero(walkwarm)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
         nc, nww, npre, nw = int(cold.sum()), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
