@@ -134,6 +134,11 @@ int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const dou
 int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon,
                  const double* d_alt, int64_t T, const double* d_C,
                  const double* d_hull_eq, int32_t F, double hull_tol, double* d_out);
+/* Arithmetic of the Legendre degree recurrences inside vi_eval_f64 for this model: 0 = fp64 (default; the reference
+ * computes in float64 throughout, sphharmlag.py:118-145), 1 = fp32 chains with everything else in fp64 - the variant
+ * BASELINE configs[4] sweeps against the 1e-6 tolerance.  Orders with an fp32 kernel: (MAXL, MAXK) = (6,4), (2,8), (12,8);
+ * others return VI_ERR_UNSUPPORTED from vi_eval_f64 while the flag is set. */
+int  vi_model_set_eval_precision(vi_model* model, int32_t chain_f32);
 /* device time (ms) of the evaluation kernel launches of the last vi_eval_f64 call on this context, from HIP
  * events recorded on the context's stream around them (the preparation kernels are excluded) */
 int  vi_eval_kernel_ms(vi_ctx* ctx, double* ms);

@@ -435,15 +435,15 @@ struct FastEval {
     const double* shC;      // LDS [TT][L*L*K] coefficient tile, [t][r = l(l+1)+m][k]
     double Lk[K];
     double acc[TT];
-    template <int l>
-    __device__ __forceinline__ void consume(const double* cur, const double* cm, const double* sm)
+    template <int l, typename CT>
+    __device__ __forceinline__ void consume(const CT* cur, const double* cm, const double* sm)
     {
         constexpr int r0 = l * (l + 1);
         constexpr int NB = L * L * K;
 #pragma unroll
         for (int m = 0; m <= l; ++m) {
-            const double pc = cur[m] * cm[m];
-            const double ps = cur[m] * sm[m];
+            const double pc = (double)cur[m] * cm[m];
+            const double ps = (double)cur[m] * sm[m];
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const double* cp = shC + t * NB + (r0 + m) * K;
@@ -464,7 +464,8 @@ struct FastEval {
 template <int L, int K, int TT, int l>
 struct ConsumeAt {
     // consume degree l if its integer part equals j (start-up phase only: j <= L)
-    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const int* nvl, int j, const double* cur,
+    template <typename CT>
+    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const int* nvl, int j, const CT* cur,
                                                const double* cm, const double* sm)
     {
         if (nvl[l] == j) E.template consume<l>(cur, cm, sm);
@@ -474,17 +475,18 @@ struct ConsumeAt {
 
 template <int L, int K, int TT, int l>
 struct MainSegments {
-    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const double* shc, const int* nvl, int& j, double x,
-                                               double* cur, double* prev, const double* cm, const double* sm)
+    template <typename CT>
+    __device__ static __forceinline__ void run(FastEval<L, K, TT>& E, const CT* shc, const int* nvl, int& j, CT x,
+                                               CT* cur, CT* prev, const double* cm, const double* sm)
     {
         const int jend = nvl[l];
         if (jend > L) {
 #pragma unroll 2
             for (; j <= jend; ++j) {
-                const double* cj = shc + j * L;
+                const CT* cj = shc + j * L;
 #pragma unroll
                 for (int m = 0; m < L; ++m) {
-                    const double nw = fma(x, cur[m], -(cj[m] * prev[m]));
+                    const CT nw = fma(x, cur[m], -(cj[m] * prev[m]));
                     prev[m] = cur[m];
                     cur[m] = nw;
                 }
@@ -495,7 +497,9 @@ struct MainSegments {
     }
 };
 
-template <int L, int K, int TT>
+// CT = arithmetic type of the Legendre chains: double, or float for the fp32 variant of BASELINE configs[4]'s tolerance
+// sweep (seeds, trigonometric and Laguerre factors and the contraction with the coefficients stay fp64)
+template <int L, int K, int TT, typename CT>
 __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, const double* __restrict__ lat,
                                                          const double* __restrict__ lon, const double* __restrict__ alt,
                                                          int tcount, const double* __restrict__ Cp,
@@ -506,10 +510,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, co
     constexpr int NB = L * L * K;
     const SphGroupDev G = M.groups[0];
     const int nj = G.nvmax + 1;
-    double* shc = sh;                                   // [nj][L]
+    CT* shc = reinterpret_cast<CT*>(sh);                // [nj][L] recurrence table in the chain's arithmetic type
     double* shC = sh + ((nj * L + 1) & ~1);             // [TT][NB]
     int* nvl = reinterpret_cast<int*>(shC + TT * NB);   // [L]
-    for (int i = threadIdx.x; i < nj * L; i += BLOCK) shc[i] = G.c[i];
+    for (int i = threadIdx.x; i < nj * L; i += BLOCK) shc[i] = (CT)G.c[i];
     for (int i = threadIdx.x; i < TT * NB; i += BLOCK) shC[i] = i < tcount * NB ? Cp[i] : 0.0;
     for (int j = threadIdx.x; j < nj; j += BLOCK) {
         const int l = G.pick[j];
@@ -542,12 +546,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, co
         cm[m] = cm[m - 1] * g.cphi - sm[m - 1] * g.sphi;
         sm[m] = sm[m - 1] * g.cphi + cm[m - 1] * g.sphi;
     }
-    const double x = g.x;
-    const double zz = 0.5 * (1.0 - x);
+    const CT x = (CT)g.x;
+    const double zz = 0.5 * (1.0 - g.x);
     const bool intseed = (G.nterms == 0);
-    double cur[L], prev[L];
+    CT cur[L], prev[L];
 #pragma unroll
-    for (int m = 0; m < L; ++m) { cur[m] = 0.0; prev[m] = 0.0; }
+    for (int m = 0; m < L; ++m) { cur[m] = (CT)0.0; prev[m] = (CT)0.0; }
     double pmm = 1.0, spow = 1.0;
     // ---- start-up: degrees j = 0 .. L, compile-time triangular structure ------------------------------
 #pragma unroll
@@ -556,18 +560,18 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, co
         for (int m = 0; m < L; ++m) {
             if (j > m + 1) {
                 if (j < nj) {
-                    const double nw = fma(x, cur[m], -(shc[j * L + m] * prev[m]));
+                    const CT nw = fma(x, cur[m], -(shc[j * L + m] * prev[m]));
                     prev[m] = cur[m];
                     cur[m] = nw;
                 }
             } else if (j == m) {
                 if (m > 0) { pmm *= -(2.0 * m - 1.0) * g.s; spow *= g.s; }
-                if (intseed) cur[m] = pmm;
-                else cur[m] = G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz);
+                if (intseed) cur[m] = (CT)pmm;
+                else cur[m] = (CT)(G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz));
             } else if (j == m + 1) {
                 prev[m] = cur[m];
-                if (intseed) cur[m] = x * (2.0 * m + 1.0) * cur[m];
-                else cur[m] = G.pref[L + m] * spow * hyp_series(G.q + (size_t)(L + m) * G.nterms, G.nterms, zz);
+                if (intseed) cur[m] = (CT)(g.x * (2.0 * m + 1.0) * pmm);
+                else cur[m] = (CT)(G.pref[L + m] * spow * hyp_series(G.q + (size_t)(L + m) * G.nterms, G.nterms, zz));
             }
         }
         ConsumeAt<L, K, TT, 0>::run(E, nvl, j, cur, cm, sm);
@@ -706,20 +710,17 @@ int launch_eval_sph(vi_model* m, int64_t Q, const double* lat, const double* lon
 }
 
 
-template <int L, int K>
+template <int L, int K, typename CT>
 int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
                          const double* Cp, const unsigned char* hull, int F, double tol, double* out)
 {
     const int N = m->N;
     const int nj = m->nvmax0 + 1;
     auto shm = [&](int TT) { return (size_t)(((nj * L + 1) & ~1) + TT * N) * sizeof(double) + L * sizeof(int) + 16; };
-    static bool attr = false;
-    if (!attr) {
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
-    }
+    // per call, not cached: the attribute is per device and several device contexts may live in one process
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 16, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 4, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_fast<L, K, 1, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     // timestep tiles of 16 / 4 / 1: the basis is recomputed once per tile, so a wide tile amortises it and the
     // contraction (2N flop per point-timestep) dominates.  Measured at 128^3, N = 144: 1.4e10 / 3.9e10 / 6.2e10
     // point-timesteps/s for tiles of 1 / 4 / 16 (a tile of 8 is slower than 16).  Whole tiles of 16 timesteps normally
@@ -728,15 +729,15 @@ int launch_eval_sph_fast(vi_model* m, int64_t Q, const double* lat, const double
     int64_t t = 0;
     while (t < T) {
         if (wide_ok && T - t >= 16) {
-            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 16>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(16), m->ctx->stream,
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 16, CT>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(16), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 16, Cp + t * N, hull, F, tol, out + t * Q);
             t += 16;
         } else if (T - t >= 4) {
-            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 4>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 4, CT>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 4, Cp + t * N, hull, F, tol, out + t * Q);
             t += 4;
         } else {
-            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 1>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(1), m->ctx->stream,
+            hipLaunchKernelGGL((k_eval_sph_fast<L, K, 1, CT>), dim3(nblocks(Q, BLOCK)), dim3(BLOCK), shm(1), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 1, Cp + t * N, hull, F, tol, out + t * Q);
             t += 1;
         }
@@ -901,6 +902,20 @@ extern "C" int vi_eval_err_f64(vi_model* m, int64_t Q, const double* d_lat, cons
     return VI_OK;
 }
 
+// Arithmetic of the Legendre degree recurrences of the fused evaluation: 0 = fp64 (default), 1 = fp32 chains (seeds,
+// trigonometric and Laguerre factors and the contraction stay fp64).  BASELINE configs[4]'s fp32-vs-fp64 tolerance sweep.
+extern "C" int vi_model_set_eval_precision(vi_model* m, int32_t chain_f32)
+{
+    VI_REQUIRE(m, "null model");
+    VI_REQUIRE(chain_f32 == 0 || chain_f32 == 1, "precision must be 0 (fp64) or 1 (fp32 chains)");
+    if (chain_f32 && m->kind != VI_MODEL_SPHHARMLAG) {
+        vi_set_error("vi_model_set_eval_precision: the fp32 variant exists for the sphharmlag model only");
+        return VI_ERR_UNSUPPORTED;
+    }
+    m->chain_f32 = chain_f32 != 0;
+    return VI_OK;
+}
+
 extern "C" int vi_transform_f64(vi_model* m, int64_t P, const double* d_lat, const double* d_lon, const double* d_alt,
                                 double* d_c0, double* d_c1, double* d_c2)
 {
@@ -969,7 +984,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
         EvalTimer timer(m->ctx);
         // whole tiles of 16 timesteps go to the matrix-core kernel (vi_eval_mfma.hip); the rest to the VALU kernels
         int64_t done = 0;
-        if (use_fast_eval()) {
+        if (use_fast_eval() && !m->chain_f32) {
             const int rc = vi_eval_sph_mfma(m, Q, d_lat, d_lon, d_alt, T, m->d_coef, d_mask, (int)F, d_out, &done);
             if (rc != VI_OK) return rc;
             if (done == T) return VI_OK;
@@ -983,8 +998,14 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
             if (rc != VI_OK || handled) return rc;
         }
         if (use_fast_eval() && m->sph.ngroups == 1 && (size_t)(m->nvmax0 + 1) * L * 8 + (size_t)4 * N * 8 < 60 * 1024) {
+            if (m->chain_f32) {     // fp32 Legendre chains (vi_model_set_eval_precision): the orders of the tolerance sweep
+                if (L == 6 && K == 4) return launch_eval_sph_fast<6, 4, float>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp);
+                if (L == 2 && K == 8) return launch_eval_sph_fast<2, 8, float>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp);
+                vi_set_error("vi_eval_f64: no fp32-chain kernel for MAXL=%d MAXK=%d", L, K);
+                return VI_ERR_UNSUPPORTED;
+            }
 #define VI_FAST(LL, KK) \
-    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp)
+    if (L == LL && K == KK) return launch_eval_sph_fast<LL, KK, double>(m, Q, d_lat, d_lon, d_alt, Tr, coef, d_mask, F, hull_tol, outp)
             VI_FAST(6, 4);
             VI_FAST(2, 8);
             VI_FAST(3, 4);

@@ -101,4 +101,5 @@ struct vi_model {
     size_t hull_bytes = 0;
     unsigned char* d_mask = nullptr;   // inside-hull byte mask of the last vi_eval grid, grow-only
     size_t mask_bytes = 0;
+    bool chain_f32 = false;      // evaluate the Legendre degree recurrences in fp32 (vi_model_set_eval_precision)
 };

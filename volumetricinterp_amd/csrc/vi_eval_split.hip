@@ -23,8 +23,8 @@ struct SplitEval {
     const double* Lk;       // [K] Laguerre factors of the point
     double* acc;            // [TT] accumulators shared by all groups
     // orders M0 .. M0+MW-1 of degree l (cur / cm / sm are indexed by m - M0)
-    template <int l>
-    __device__ __forceinline__ void consume(const double* cur, const double* cm, const double* sm)
+    template <int l, typename CT>
+    __device__ __forceinline__ void consume(const CT* cur, const double* cm, const double* sm)
     {
         constexpr int r0 = l * (l + 1);
         constexpr int NB = L * L * K;
@@ -32,8 +32,8 @@ struct SplitEval {
         for (int mm = 0; mm < MW; ++mm) {
             const int m = M0 + mm;
             if (m <= l) {
-                const double pc = cur[mm] * cm[mm];
-                const double ps = cur[mm] * sm[mm];
+                const double pc = (double)cur[mm] * cm[mm];
+                const double ps = (double)cur[mm] * sm[mm];
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     const double* cp = shC + t * NB + (r0 + m) * K;
@@ -54,7 +54,8 @@ struct SplitEval {
 
 template <int L, class Ev, int l, int M0>
 struct SplitPickAt {
-    __device__ static __forceinline__ void run(Ev& E, const int* nvl, int j, const double* cur, const double* cm,
+    template <typename CT>
+    __device__ static __forceinline__ void run(Ev& E, const int* nvl, int j, const CT* cur, const double* cm,
                                                const double* sm)
     {
         if constexpr (l >= M0) {
@@ -66,17 +67,18 @@ struct SplitPickAt {
 
 template <int L, class Ev, int l, int M0, int MW>
 struct SplitSegments {
-    __device__ static __forceinline__ void run(Ev& E, const double* shc, const int* nvl, int& j, double x, double* cur,
-                                               double* prev, const double* cm, const double* sm)
+    template <typename CT>
+    __device__ static __forceinline__ void run(Ev& E, const CT* shc, const int* nvl, int& j, CT x, CT* cur,
+                                               CT* prev, const double* cm, const double* sm)
     {
         const int jend = nvl[l];
         if (jend > L) {
 #pragma unroll 2
             for (; j <= jend; ++j) {
-                const double* cj = shc + j * L + M0;
+                const CT* cj = shc + j * L + M0;
 #pragma unroll
                 for (int mm = 0; mm < MW; ++mm) {
-                    const double nw = fma(x, cur[mm], -(cj[mm] * prev[mm]));
+                    const CT nw = fma(x, cur[mm], -(cj[mm] * prev[mm]));
                     prev[mm] = cur[mm];
                     cur[mm] = nw;
                 }
@@ -87,9 +89,10 @@ struct SplitSegments {
     }
 };
 
-// one group of orders M0 .. M0+MW-1
-template <int L, int K, int TT, int M0, int MW>
-__device__ __forceinline__ void run_group(const SphGroupDev& G, const Geom& g, const double* shc, const double* shC,
+// one group of orders M0 .. M0+MW-1; CT = arithmetic type of the Legendre chains (double, or float for the fp32 variant:
+// seeds, trigonometric factors, Laguerre factors and the contraction stay fp64)
+template <int L, int K, int TT, int M0, int MW, typename CT>
+__device__ __forceinline__ void run_group(const SphGroupDev& G, const Geom& g, const CT* shc, const double* shC,
                                           const int* nvl, int nj, const double* Lk, double* acc)
 {
     using Ev = SplitEval<L, K, TT, M0, MW>;
@@ -117,12 +120,12 @@ __device__ __forceinline__ void run_group(const SphGroupDev& G, const Geom& g, c
     double pmm = 1.0, spow = 1.0;
 #pragma unroll
     for (int i = 1; i < M0; ++i) { pmm *= -(2.0 * i - 1.0) * g.s; spow *= g.s; }
-    const double x = g.x;
-    const double zz = 0.5 * (1.0 - x);
+    const CT x = (CT)g.x;
+    const double zz = 0.5 * (1.0 - g.x);
     const bool intseed = (G.nterms == 0);
-    double cur[MW], prev[MW];
+    CT cur[MW], prev[MW];
 #pragma unroll
-    for (int mm = 0; mm < MW; ++mm) { cur[mm] = 0.0; prev[mm] = 0.0; }
+    for (int mm = 0; mm < MW; ++mm) { cur[mm] = (CT)0.0; prev[mm] = (CT)0.0; }
     // ---- start-up: degrees j = 0 .. L, compile-time triangular structure ----------------------------------
 #pragma unroll
     for (int j = 0; j <= L; ++j) {
@@ -131,18 +134,18 @@ __device__ __forceinline__ void run_group(const SphGroupDev& G, const Geom& g, c
             const int m = M0 + mm;
             if (j > m + 1) {
                 if (j < nj) {
-                    const double nw = fma(x, cur[mm], -(shc[j * L + m] * prev[mm]));
+                    const CT nw = fma(x, cur[mm], -(shc[j * L + m] * prev[mm]));
                     prev[mm] = cur[mm];
                     cur[mm] = nw;
                 }
             } else if (j == m) {
                 if (m > 0) { pmm *= -(2.0 * m - 1.0) * g.s; spow *= g.s; }
-                if (intseed) cur[mm] = pmm;
-                else cur[mm] = G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz);
+                if (intseed) cur[mm] = (CT)pmm;
+                else cur[mm] = (CT)(G.pref[m] * spow * hyp_series(G.q + (size_t)m * G.nterms, G.nterms, zz));
             } else if (j == m + 1) {
                 prev[mm] = cur[mm];
-                if (intseed) cur[mm] = x * (2.0 * m + 1.0) * cur[mm];
-                else cur[mm] = G.pref[L + m] * spow * hyp_series(G.q + (size_t)(L + m) * G.nterms, G.nterms, zz);
+                if (intseed) cur[mm] = (CT)(g.x * (2.0 * m + 1.0) * pmm);
+                else cur[mm] = (CT)(G.pref[L + m] * spow * hyp_series(G.q + (size_t)(L + m) * G.nterms, G.nterms, zz));
             }
         }
         SplitPickAt<L, Ev, 0, M0>::run(E, nvl, j, cur, cm, sm);
@@ -154,16 +157,17 @@ __device__ __forceinline__ void run_group(const SphGroupDev& G, const Geom& g, c
 
 template <int L, int K, int TT, int NH, int G_>
 struct GroupLoop {
-    __device__ static __forceinline__ void run(const SphGroupDev& G, const Geom& g, const double* shc, const double* shC,
+    template <typename CT>
+    __device__ static __forceinline__ void run(const SphGroupDev& G, const Geom& g, const CT* shc, const double* shC,
                                                const int* nvl, int nj, const double* Lk, double* acc)
     {
         constexpr int MW = L / NH;
-        run_group<L, K, TT, G_ * MW, MW>(G, g, shc, shC, nvl, nj, Lk, acc);
+        run_group<L, K, TT, G_ * MW, MW, CT>(G, g, shc, shC, nvl, nj, Lk, acc);
         if constexpr (G_ + 1 < NH) GroupLoop<L, K, TT, NH, G_ + 1>::run(G, g, shc, shC, nvl, nj, Lk, acc);
     }
 };
 
-template <int L, int K, int TT, int NH>
+template <int L, int K, int TT, int NH, typename CT>
 __global__ __launch_bounds__(BLOCK) void k_eval_sph_split(SphDev M, int64_t Q, const double* __restrict__ lat,
                                                           const double* __restrict__ lon, const double* __restrict__ alt,
                                                           int tcount, const double* __restrict__ Cp,
@@ -175,10 +179,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_split(SphDev M, int64_t Q, c
     constexpr int NB = L * L * K;
     const SphGroupDev G = M.groups[0];
     const int nj = G.nvmax + 1;
-    double* shc = sh;                                   // [nj][L]
+    CT* shc = reinterpret_cast<CT*>(sh);                // [nj][L] recurrence table in the chain's arithmetic type
     double* shC = sh + ((nj * L + 1) & ~1);             // [TT][NB]
     int* nvl = reinterpret_cast<int*>(shC + TT * NB);   // [L]
-    for (int i = threadIdx.x; i < nj * L; i += BLOCK) shc[i] = G.c[i];
+    for (int i = threadIdx.x; i < nj * L; i += BLOCK) shc[i] = (CT)G.c[i];
     for (int i = threadIdx.x; i < TT * NB; i += BLOCK) shC[i] = i < tcount * NB ? Cp[i] : 0.0;
     for (int j = threadIdx.x; j < nj; j += BLOCK) {
         const int l = G.pick[j];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_split(SphDev M, int64_t Q, c
     double acc[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = 0.0;
-    GroupLoop<L, K, TT, NH, 0>::run(G, g, shc, shC, nvl, nj, Lk, acc);
+    GroupLoop<L, K, TT, NH, 0>::template run<CT>(G, g, shc, shC, nvl, nj, Lk, acc);
     const double Ez = exp(-0.5 * g.z);
     if (q < Q) {
 #pragma unroll
@@ -214,29 +218,26 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_split(SphDev M, int64_t Q, c
 
 inline unsigned nblocks_s(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
-template <int L, int K, int NH>
+template <int L, int K, int NH, typename CT>
 int launch_split(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
                  const double* Cp, const unsigned char* hull, int F, double* out)
 {
     const int N = m->N;
     const int nj = m->nvmax0 + 1;
     auto shm = [&](int TT) { return (size_t)(((nj * L + 1) & ~1) + TT * N) * sizeof(double) + L * sizeof(int) + 16; };
-    static bool attr = false;
-    if (!attr) {
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_split<L, K, 4, NH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   64 * 1024));
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_split<L, K, 1, NH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   64 * 1024));
-        attr = true;
-    }
+    // per call, not cached: the attribute is per device and several device contexts may live in one process
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_split<L, K, 4, NH, CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               64 * 1024));
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_split<L, K, 1, NH, CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               64 * 1024));
     int64_t t = 0;
     while (t < T) {
         if (T - t >= 4 && shm(4) <= 60 * 1024) {
-            hipLaunchKernelGGL((k_eval_sph_split<L, K, 4, NH>), dim3(nblocks_s(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
+            hipLaunchKernelGGL((k_eval_sph_split<L, K, 4, NH, CT>), dim3(nblocks_s(Q, BLOCK)), dim3(BLOCK), shm(4), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 4, Cp + t * N, hull, F, out + t * Q);
             t += 4;
         } else {
-            hipLaunchKernelGGL((k_eval_sph_split<L, K, 1, NH>), dim3(nblocks_s(Q, BLOCK)), dim3(BLOCK), shm(1), m->ctx->stream,
+            hipLaunchKernelGGL((k_eval_sph_split<L, K, 1, NH, CT>), dim3(nblocks_s(Q, BLOCK)), dim3(BLOCK), shm(1), m->ctx->stream,
                                m->sph, Q, lat, lon, alt, 1, Cp + t * N, hull, F, out + t * Q);
             t += 1;
         }
@@ -271,10 +272,13 @@ int vi_eval_sph_split(vi_model* m, int64_t Q, const double* lat, const double* l
     // measured at MAXK 8 x MAXL 12, 128^3 points: 1.93 ms with all twelve chains at once (k_eval_sph_fast), 1.13 ms in two
     // groups of six (190 VGPRs, two waves per SIMD), 0.73 ms in three groups of four (115 VGPRs, four waves), 0.77 ms in
     // four groups of three
-    if (L == 12 && K == 8 && nh == 2) rc = launch_split<12, 8, 2>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
-    else if (L == 12 && K == 8 && nh == 4) rc = launch_split<12, 8, 4>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
-    else if (L == 12 && K == 8) rc = launch_split<12, 8, 3>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
-    else if (L == 12 && K == 2) rc = launch_split<12, 2, 3>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+    if (m->chain_f32) {          // fp32 Legendre chains (vi_model_set_eval_precision)
+        if (L == 12 && K == 8) rc = launch_split<12, 8, 3, float>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+        else return VI_OK;
+    } else if (L == 12 && K == 8 && nh == 2) rc = launch_split<12, 8, 2, double>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+    else if (L == 12 && K == 8 && nh == 4) rc = launch_split<12, 8, 4, double>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+    else if (L == 12 && K == 8) rc = launch_split<12, 8, 3, double>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
+    else if (L == 12 && K == 2) rc = launch_split<12, 2, 3, double>(m, Q, lat, lon, alt, T, Cp, hull, F, out);
     // (the default order gains nothing from groups: 0.155 ms at once, 0.171 / 0.165 ms in two / three groups)
     else return VI_OK;
     if (rc == VI_OK) *handled = 1;

@@ -28,6 +28,15 @@ class DeviceModel(object):
         self.handle()
         return self._ctx
 
+    def set_eval_precision(self, chains='f64'):
+        """Arithmetic of the Legendre degree recurrences of the fused evaluation (vi_model_set_eval_precision):
+        'f64' (default, the reference's float64) or 'f32' - fp32 chains, everything else fp64 (BASELINE configs[4]'s
+        tolerance sweep; it misses the 1e-6 tolerance)."""
+        if chains not in ('f64', 'f32'):
+            raise ValueError("chains must be 'f64' or 'f32'")
+        _lib.check(_lib.lib.vi_model_set_eval_precision(self.handle(), 1 if chains == 'f32' else 0),
+                   'vi_model_set_eval_precision')
+
     def __del__(self):
         try:
             if self._handle is not None and self._ctx is not None and self._ctx.handle:
