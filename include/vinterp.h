@@ -152,10 +152,16 @@ int  vi_solve_timing(vi_ctx* ctx, int enable, int64_t* launches, int64_t* system
  * all launches since vi_solve_timing(enable = 1); read it BEFORE the next vi_solve_timing call with enable >= 0,
  * which resets it.  The unit the LDS roofline of the eigen-solve kernel is priced in (bench.py). */
 int  vi_solve_rounds(vi_ctx* ctx, int64_t* rounds);
-/* host-pointer convenience form of the same call */
+/* host-pointer form of the same call (what Estimate.__call__ uses): chunked, coordinates up on one stream while densities
+ * come down on another; the staging buffers live on the model.  h_out rows have length Q. */
 int  vi_eval_f64_host(vi_model* model, int64_t Q, const double* h_lat, const double* h_lon,
                       const double* h_alt, int64_t T, const double* h_C,
                       const double* h_hull_eq, int32_t F, double hull_tol, double* h_out);
+
+/* page-locked host memory: arrays handed to vi_eval_f64_host from it move at the full rate of the link in both directions
+ * at once (pageable arrays go through the runtime's own staging) */
+int  vi_host_alloc(size_t bytes, void** out);
+int  vi_host_free(void* p);
 
 /* ---- fit: replaces Interpolate.eval_C (interpolate.py:432-469) -----------------------------
  * Normal equations for T records sharing one basis matrix (records differ only in W and b;

@@ -80,6 +80,8 @@ _sig('vi_eval_f64_host', C.c_int, VOIDP, I64, c_double_p, c_double_p, c_double_p
 
 _sig('vi_eval_kernel_ms', C.c_int, VOIDP, c_double_p)
 _sig('vi_model_set_eval_precision', C.c_int, VOIDP, C.c_int32)
+_sig('vi_host_alloc', C.c_int, C.c_size_t, C.POINTER(VOIDP))
+_sig('vi_host_free', C.c_int, VOIDP)
 _sig('vi_solve_timing', C.c_int, VOIDP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
      c_double_p, c_double_p)
 _sig('vi_solve_rounds', C.c_int, VOIDP, C.POINTER(C.c_int64))
@@ -88,7 +90,7 @@ _sig('vi_rccl_init', C.c_int, VOIDP, C.c_int, C.c_int, C.c_char_p)
 _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
-EXPORTS = ['vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
+EXPORTS = ['vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
            'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']
@@ -223,3 +225,29 @@ def get_context(device=None):
             ctx = Context(device % n)
             _default_ctx[device] = ctx
         return ctx
+
+
+class _PinnedOwner(object):
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr is not None:
+                lib.vi_host_free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """An uninitialised ndarray in page-locked host memory (vi_host_alloc): grids and outputs kept in such arrays move
+    to and from the GPU at the full rate of the link, both directions at once, inside Estimate.__call__ /
+    evaluate_coeffs(out=...).  The memory is released when the last view of the array is gone."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64))
+    p = VOIDP()
+    check(lib.vi_host_alloc(n * dtype.itemsize, C.byref(p)), 'vi_host_alloc')
+    buf = (C.c_byte * max(1, n * dtype.itemsize)).from_address(p.value)
+    buf._vi_owner = _PinnedOwner(p)               # every view keeps `buf` (its .base chain) and with it the owner alive
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)

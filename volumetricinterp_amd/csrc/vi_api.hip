@@ -270,6 +270,13 @@ extern "C" void vi_model_destroy(vi_model* m)
     if (m->d_coef) (void)hipFree(m->d_coef);
     if (m->d_hull) (void)hipFree(m->d_hull);
     if (m->d_mask) (void)hipFree(m->d_mask);
+    if (m->h_din) (void)hipFree(m->h_din);
+    if (m->h_dC) (void)hipFree(m->h_dC);
+    if (m->h_dhull) (void)hipFree(m->h_dhull);
+    if (m->h_dout) (void)hipFree(m->h_dout);
+    if (m->h_stream2) (void)hipStreamDestroy(m->h_stream2);
+    for (int i = 0; i < 2; ++i)
+        if (m->h_ev[i]) (void)hipEventDestroy(m->h_ev[i]);
     delete m;
 }
 
@@ -349,7 +356,24 @@ extern "C" int vi_model_create(vi_ctx* c, const vi_model_desc* d, vi_model** out
     return VI_OK;
 }
 
-// host-pointer convenience form of vi_eval_f64
+// host-pointer form of vi_eval_f64 (what Estimate.__call__ uses: the reference hands over NumPy arrays).
+// The device staging buffers live on the model and only grow (the first version paid four hipMalloc / hipFree pairs
+// per call).  The grid is processed in chunks: the coordinates of chunk c+1 go up on the context's stream while the
+// densities of chunk c come down on a second stream, so the two directions of the link overlap - fully when the caller's
+// arrays are page-locked (vi_host_alloc), as far as the runtime's own staging allows when they are pageable.
+namespace {
+int grow(double** p, size_t* have, size_t need)
+{
+    if (need <= *have) return VI_OK;
+    if (*p) VI_HIP(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    VI_HIP(hipMalloc((void**)p, need));
+    *have = need;
+    return VI_OK;
+}
+}  // namespace
+
 extern "C" int vi_eval_f64_host(vi_model* m, int64_t Q, const double* h_lat, const double* h_lon, const double* h_alt,
                                 int64_t T, const double* h_C, const double* h_hull_eq, int32_t F, double hull_tol,
                                 double* h_out)
@@ -359,40 +383,67 @@ extern "C" int vi_eval_f64_host(vi_model* m, int64_t Q, const double* h_lat, con
     if (Q == 0 || T == 0) return VI_OK;
     vi_ctx* c = m->ctx;
     VI_HIP(hipSetDevice(c->device));
-    const size_t qb = (size_t)Q * sizeof(double);
-    double *d_in = nullptr, *d_C = nullptr, *d_hull = nullptr, *d_out = nullptr;
-    int rc = VI_OK;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(c->stream);
-        if (d_in) (void)hipFree(d_in);
-        if (d_C) (void)hipFree(d_C);
-        if (d_hull) (void)hipFree(d_hull);
-        if (d_out) (void)hipFree(d_out);
-    };
-#define VI_TRY(call)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            vi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));    \
-            cleanup();                                                                            \
-            return VI_ERR_HIP;                                                                    \
-        }                                                                                         \
-    } while (0)
-    VI_TRY(hipMalloc((void**)&d_in, 3 * qb));
-    VI_TRY(hipMalloc((void**)&d_C, (size_t)T * m->N * sizeof(double)));
-    VI_TRY(hipMalloc((void**)&d_out, (size_t)T * qb));
-    if (F > 0) VI_TRY(hipMalloc((void**)&d_hull, (size_t)F * 4 * sizeof(double)));
-    VI_TRY(hipMemcpyAsync(d_in, h_lat, qb, hipMemcpyHostToDevice, c->stream));
-    VI_TRY(hipMemcpyAsync(d_in + Q, h_lon, qb, hipMemcpyHostToDevice, c->stream));
-    VI_TRY(hipMemcpyAsync(d_in + 2 * Q, h_alt, qb, hipMemcpyHostToDevice, c->stream));
-    VI_TRY(hipMemcpyAsync(d_C, h_C, (size_t)T * m->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (F > 0) VI_TRY(hipMemcpyAsync(d_hull, h_hull_eq, (size_t)F * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = vi_eval_f64(m, Q, d_in, d_in + Q, d_in + 2 * Q, T, d_C, d_hull, F, hull_tol, d_out);
-    if (rc == VI_OK) {
-        VI_TRY(hipMemcpyAsync(h_out, d_out, (size_t)T * qb, hipMemcpyDeviceToHost, c->stream));
-        VI_TRY(hipStreamSynchronize(c->stream));
+    // chunk: large enough to keep the evaluation kernel efficient (>= 2048 workgroups), small enough for several chunks
+    // to be in flight at the BASELINE grid sizes; the whole per-chunk output (T rows) must fit the staging buffer
+    int64_t chunk = (int64_t)1 << 19;
+    while (chunk > 4096 && (size_t)T * chunk * sizeof(double) > ((size_t)1 << 30)) chunk >>= 1;
+    if (chunk > Q) chunk = Q;
+    const int64_t nchunk = (Q + chunk - 1) / chunk;
+    VI_HIP(hipStreamSynchronize(c->stream));          // nothing of an earlier call may still use the staging buffers
+    int rc;
+    if ((rc = grow(&m->h_din, &m->h_din_bytes, (size_t)2 * 3 * chunk * sizeof(double))) != VI_OK) return rc;
+    if ((rc = grow(&m->h_dC, &m->h_dC_bytes, (size_t)T * m->N * sizeof(double))) != VI_OK) return rc;
+    if ((rc = grow(&m->h_dout, &m->h_dout_bytes, (size_t)2 * T * chunk * sizeof(double))) != VI_OK) return rc;
+    if (F > 0 && (rc = grow(&m->h_dhull, &m->h_dhull_bytes, (size_t)F * 4 * sizeof(double))) != VI_OK) return rc;
+    if (!m->h_stream2) {
+        VI_HIP(hipStreamCreateWithFlags(&m->h_stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) VI_HIP(hipEventCreateWithFlags(&m->h_ev[i], hipEventDisableTiming));
     }
-#undef VI_TRY
-    cleanup();
+    VI_HIP(hipMemcpyAsync(m->h_dC, h_C, (size_t)T * m->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (F > 0)
+        VI_HIP(hipMemcpyAsync(m->h_dhull, h_hull_eq, (size_t)F * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipEvent_t down[2] = {nullptr, nullptr};          // "the download out of slot s has finished" (stream2)
+    hipEvent_t evdown[2];
+    for (int i = 0; i < 2; ++i) VI_HIP(hipEventCreateWithFlags(&evdown[i], hipEventDisableTiming));
+    rc = VI_OK;
+    for (int64_t k = 0; k < nchunk && rc == VI_OK; ++k) {
+        const int s = (int)(k & 1);
+        const int64_t q0 = k * chunk;
+        const int64_t qc = (Q - q0) < chunk ? (Q - q0) : chunk;
+        double* din = m->h_din + (size_t)s * 3 * chunk;
+        double* dout = m->h_dout + (size_t)s * T * chunk;
+        // slot s was last used by chunk k - 2: its download must be over before the kernel of chunk k overwrites dout
+        if (down[s]) VI_HIP(hipStreamWaitEvent(c->stream, down[s], 0));
+        VI_HIP(hipMemcpyAsync(din, h_lat + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        VI_HIP(hipMemcpyAsync(din + chunk, h_lon + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        VI_HIP(hipMemcpyAsync(din + 2 * chunk, h_alt + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        rc = vi_eval_f64(m, qc, din, din + chunk, din + 2 * chunk, T, m->h_dC, F > 0 ? m->h_dhull : nullptr, F, hull_tol, dout);
+        if (rc != VI_OK) break;
+        VI_HIP(hipEventRecord(m->h_ev[s], c->stream));
+        VI_HIP(hipStreamWaitEvent(m->h_stream2, m->h_ev[s], 0));
+        // device rows have length qc (the kernel wrote out[t * qc + q]); host rows have length Q
+        VI_HIP(hipMemcpy2DAsync(h_out + q0, (size_t)Q * sizeof(double), dout, (size_t)qc * sizeof(double),
+                                (size_t)qc * sizeof(double), (size_t)T, hipMemcpyDeviceToHost, m->h_stream2));
+        VI_HIP(hipEventRecord(evdown[s], m->h_stream2));
+        down[s] = evdown[s];
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(m->h_stream2);
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(evdown[i]);
     return rc;
+}
+
+// Page-locked host memory for callers that want the two directions of vi_eval_f64_host to overlap completely.
+extern "C" int vi_host_alloc(size_t bytes, void** out)
+{
+    VI_REQUIRE(out, "null argument");
+    *out = nullptr;
+    VI_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return VI_OK;
+}
+
+extern "C" int vi_host_free(void* p)
+{
+    if (p) VI_HIP(hipHostFree(p));
+    return VI_OK;
 }

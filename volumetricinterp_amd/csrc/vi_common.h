@@ -102,4 +102,11 @@ struct vi_model {
     unsigned char* d_mask = nullptr;   // inside-hull byte mask of the last vi_eval grid, grow-only
     size_t mask_bytes = 0;
     bool chain_f32 = false;      // evaluate the Legendre degree recurrences in fp32 (vi_model_set_eval_precision)
+    // staging of vi_eval_f64_host, grow-only: device coordinates / coefficients / facets / output, second stream + events
+    double* h_din = nullptr;     size_t h_din_bytes = 0;
+    double* h_dC = nullptr;      size_t h_dC_bytes = 0;
+    double* h_dhull = nullptr;   size_t h_dhull_bytes = 0;
+    double* h_dout = nullptr;    size_t h_dout_bytes = 0;
+    hipStream_t h_stream2 = nullptr;
+    hipEvent_t h_ev[2] = {nullptr, nullptr};
 };

@@ -86,8 +86,9 @@ class Estimate(object):
         out = self.evaluate_coeffs(np.asarray(C, dtype=np.float64)[None, :], gdlat, gdlon, gdalt, check_hull)
         return out[0].reshape(gdlat.shape)
 
-    def evaluate_coeffs(self, C, gdlat, gdlon, gdalt, check_hull=True):
-        """out[t] = density of coefficient row C[t] at the points; (T, Q)."""
+    def evaluate_coeffs(self, C, gdlat, gdlon, gdalt, check_hull=True, out=None):
+        """out[t] = density of coefficient row C[t] at the points; (T, Q).  `out`: optional C-contiguous float64 (T, Q)
+        array to write into (e.g. from _lib.pinned_empty, like the coordinate arrays, for full-rate transfers)."""
         C = np.ascontiguousarray(C, dtype=np.float64)
         lat = np.ascontiguousarray(np.asarray(gdlat, dtype=np.float64).ravel())
         lon = np.ascontiguousarray(np.asarray(gdlon, dtype=np.float64).ravel())
@@ -97,7 +98,10 @@ class Estimate(object):
         T, Q = C.shape[0], lat.size
         if C.shape[1] != self.model.nbasis:
             raise ValueError('coefficient vector length %d != nbasis %d' % (C.shape[1], self.model.nbasis))
-        out = np.empty((T, Q), dtype=np.float64)
+        if out is None:
+            out = np.empty((T, Q), dtype=np.float64)
+        elif out.shape != (T, Q) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous float64 array of shape (%d, %d)' % (T, Q))
         if Q == 0 or T == 0:
             return out
         h = self.model.handle()
