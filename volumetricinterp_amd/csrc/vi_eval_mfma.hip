@@ -290,12 +290,8 @@ int launch_tile(vi_model* m, int64_t Q, const double* lat, const double* lon, co
 {
     const int nj = m->nvmax0 + 1;
     const size_t shm = (size_t)(((nj * L + 1) & ~1) + NT * L * L * KQ * 64) * sizeof(double) + L * sizeof(int) + 16;
-    static size_t attr = 0;
-    if (shm > attr) {
-        VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_mfma<L, KQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)shm));
-        attr = shm;
-    }
+    // per call, not cached: the attribute is per device and several device contexts may live in one process
+    VI_HIP(hipFuncSetAttribute((const void*)k_eval_sph_mfma<L, KQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     // points per workgroup: enough groups of 256 to amortise the coefficient image, yet >= ~8 workgroups per CU
     int ngrp = 8;
     while (ngrp > 1 && (Q + MBLOCK * ngrp - 1) / (MBLOCK * ngrp) < (int64_t)8 * m->ctx->n_cu) ngrp >>= 1;

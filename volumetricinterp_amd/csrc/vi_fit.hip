@@ -611,40 +611,50 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     VI_HIP(hipSetDevice(c->device));
     const int NN = N * N;
     const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
-    void* ws = nullptr;
     const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * NN * sizeof(double);
-    int rc = vi_ctx_workspace(c, (size_t)B * per + 1024, &ws);
+    // chunks of records, so that the rotation logs and temporaries stay within 4 GiB of workspace (4.3 MB per record at
+    // N = 144: 10 000 records at once would ask for 43 GB)
+    int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
+    if (Bc < 1) Bc = 1;
+    if (Bc > B) Bc = B;
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)Bc * per + 1024, &ws);
     if (rc != VI_OK) return rc;
-    char* wp = (char*)ws + (size_t)B * logb;
+    char* wp = (char*)ws + (size_t)Bc * logb;
     double* scl = (double*)wp;
-    double* lam = scl + B;
-    double* T0 = lam + (size_t)B * N;      // X0, later AWA[rec]
-    double* T1 = T0 + (size_t)B * NN;
-    int* nrd = (int*)(T1 + (size_t)B * NN);
-    hipLaunchKernelGGL(k_form_system, dim3((unsigned)B), dim3(256), 0, c->stream, NN, d_AWA, d_rec, d_alpha0, d_R, T0);
-    hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, NN, T0, scl);
-    VI_HIP(hipGetLastError());
-    rc = vi_jacobi_solve(c, B, N, T0, scl, d_y, d_rec, rcond, d_C, d_rank, ws, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd,
-                         JACOBI_FLOOR_COLD);
-    if (rc != VI_OK) return rc;
-    rc = vi_jacobi_vectors(c, B, N, ws, JACOBI_MAX_SWEEPS, nrd, d_V);
-    if (rc != VI_OK) return rc;
+    double* lam = scl + Bc;
+    double* T0 = lam + (size_t)Bc * N;     // X0, later AWA[rec]
+    double* T1 = T0 + (size_t)Bc * NN;
+    int* nrd = (int*)(T1 + (size_t)Bc * NN);
     const double one = 1.0, zero = 0.0;
     const rocblas_stride sN = (rocblas_stride)NN;
-    // D1 = V^T (AWA V)
-    hipLaunchKernelGGL(k_form_system, dim3((unsigned)B), dim3(256), 0, c->stream, NN, d_AWA, d_rec, nullptr, nullptr, T0);
-    VI_HIP(hipGetLastError());
-    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, T0, N,
-                                             sN, d_V, N, sN, &zero, T1, N, sN, (rocblas_int)B));
-    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
-                                             d_V, N, sN, T1, N, sN, &zero, d_D1, N, sN, (rocblas_int)B));
-    // D2 = V^T (R V)
-    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, d_R, N,
-                                             0, d_V, N, sN, &zero, T1, N, sN, (rocblas_int)B));
-    VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
-                                             d_V, N, sN, T1, N, sN, &zero, d_D2, N, sN, (rocblas_int)B));
-    hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)B), dim3(256), 0, c->stream, N, d_V, nullptr, d_y, d_rec, d_yt);
-    VI_HIP(hipGetLastError());
+    for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+        const int32_t* recc = d_rec + i0;
+        double* Vc = d_V + i0 * NN;
+        hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, d_alpha0 + i0, d_R, T0);
+        hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, T0, scl);
+        VI_HIP(hipGetLastError());
+        rc = vi_jacobi_solve(c, bc, N, T0, scl, d_y, recc, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
+                             JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd, JACOBI_FLOOR_COLD);
+        if (rc != VI_OK) return rc;
+        rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, Vc);
+        if (rc != VI_OK) return rc;
+        // D1 = V^T (AWA V)
+        hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, T0);
+        VI_HIP(hipGetLastError());
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, T0, N,
+                                                 sN, Vc, N, sN, &zero, T1, N, sN, (rocblas_int)bc));
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
+                                                 Vc, N, sN, T1, N, sN, &zero, d_D1 + i0 * NN, N, sN, (rocblas_int)bc));
+        // D2 = V^T (R V)
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, d_R, N,
+                                                 0, Vc, N, sN, &zero, T1, N, sN, (rocblas_int)bc));
+        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
+                                                 Vc, N, sN, T1, N, sN, &zero, d_D2 + i0 * NN, N, sN, (rocblas_int)bc));
+        hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vc, nullptr, d_y, recc, d_yt + i0 * N);
+        VI_HIP(hipGetLastError());
+    }
     return VI_OK;
 }
 
