@@ -137,18 +137,17 @@ class _PerturbedBasis(object):
         return A * (1 + 1e-14 * self._rng.standard_normal(A.shape))
 
 
-@pytest.mark.parametrize('maxk,maxl,reg,seed', [(8, 2, 'curvature', 80), (8, 2, '0thorder', 81), (8, 2, 'curvature', 82),
-                                                 (4, 3, '0thorder', 77)])
+@pytest.mark.parametrize('maxk,maxl,reg,seed', [(8, 2, 'curvature', 80), (8, 2, '0thorder', 81), (8, 2, 'curvature', 82)])
 def test_fresh_records_vs_oracle(tmp_path, maxk, maxl, reg, seed):
     """Parity beyond the committed fixtures: fresh geometry and records, GPU fit against the CPU oracle on identical
     inputs.  Every record is first screened the way the fixtures were: the oracle is rerun with 1e-14 relative noise on
-    its basis and the record only counts if its coefficients move by s < 1e-5; the GPU must then agree within
-    max(1e-6, 10 s).  (Measured: at MAXK 8, MAXL 2 s is 1e-9..1e-6; at (2,3) 1e-8..1e-4, one draw of s not bounding the next, so that
+    its basis and the record only counts if its coefficients move by s < 1e-6; the GPU must then agree within
+    max(1e-6, 10 s) <= 1e-5.  (Measured: at MAXK 8, MAXL 2 s is 1e-9..1e-6; at (2,3) 1e-8..1e-4, one draw of s not bounding the next, so that
     order is not used; at (4,3) and (3,4) 1e-4..1e-2: X(alpha) there has eigenvalues a few eps * lambda_max - 4.96e-16
     kept, 1.95e-16 dropped at the root of record 0 - which LAPACK resolves with absolute error eps * sigma_max, i.e. ~50 %
     relative, and whose 1/lambda dominates |C|; the Jacobi solver resolves them to full relative accuracy, so GPU and
-    oracle differ by O(1..10) in |C| while chi^2 agrees.  Such orders are skipped, as the default order is in DESIGN.md
-    section 2.)"""
+    oracle differ by O(1..10) in |C| while chi^2 agrees.  Such orders are not run here - no record of them passes the
+    screen; the default order has its own test, test_gpu_default_order.py.)"""
     import re
     import warnings
     import oracle
@@ -178,7 +177,7 @@ def test_fresh_records_vs_oracle(tmp_path, maxk, maxl, reg, seed):
             assert np.isnan(a) and np.all(np.isnan(res['Coeffs'][t])), t
             continue
         sn = rel(Cp[t], C[t]) if np.all(np.isfinite(Cp[t])) else float('inf')
-        if not sn < 1e-5:
+        if not sn < 1e-6:
             print('[order (%d,%d) %s record %d] not screened: oracle self-noise %.1e; GPU vs oracle rel(C) %.1e' %
                   (maxk, maxl, reg, t, sn, rel(res['Coeffs'][t], C[t])))
             continue
@@ -190,8 +189,7 @@ def test_fresh_records_vs_oracle(tmp_path, maxk, maxl, reg, seed):
             assert abs(math.log10(a) - math.log10(a_ref)) <= max(1e-7, tol), t
         assert rel(res['Coeffs'][t], C[t]) <= tol, (t, sn)
         assert abs(res['chi_sq'][t] - c2[t]) <= max(1e-6, tol) * c2[t]
-    if checked < 2:
-        pytest.skip('the oracle does not reproduce itself at this order (fewer than 2 of %d records pass the screen)' % T)
+    assert checked >= 2, 'fewer than 2 of %d records passed the screen' % T
 
 
 def test_fit_edge_outcomes(tmp_path):
@@ -256,35 +254,6 @@ def test_rbf_fit_no_regularisation(tmp_path):
         assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 5e-2
 
 
-def test_default_order_report(tmp_path, capsys):
-    """Default order (N = 144): the reference does not reproduce itself (self-noise 7e-2 .. 5e-1 on C),
-    so this reports the build's deviation next to that noise and gates only the stable quantities."""
-    f = load_golden('fit_default')
-    regm, reg = reg_of(f)
-    it = make_interp(tmp_path, str(f['cfg']))
-    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
-    from volumetricinterp_amd.estimate import Estimate
-    from volumetricinterp_amd import synth
-    es_a = Estimate.from_arrays(res['Coeffs'], None, f['utime'], f['hull_vert'], str(f['cfg']))
-    es_b = Estimate.from_arrays(f['Coeffs'], None, f['utime'], f['hull_vert'], str(f['cfg']))
-    g = synth.query_grid(8)
-    for t in range(f['value'].shape[0]):
-        dens_a = es_a.evaluate_coeffs(res['Coeffs'][t:t + 1], *g, check_hull=True)[0]
-        dens_b = es_b.evaluate_coeffs(f['Coeffs'][t:t + 1], *g, check_hull=True)[0]
-        ok = np.isfinite(dens_b)
-        with capsys.disabled():
-            print('\n[default order, record %d] rel(C)=%.2e (reference self-noise %.2e)  rel(density in hull)=%.2e  '
-                  'log10 alpha %.6f vs %.6f  chi2 %.6f vs %.6f'
-                  % (t, rel(res['Coeffs'][t], f['Coeffs'][t]), f['self_noise'][t], rel(dens_a[ok], dens_b[ok]),
-                     math.log10(res['reg_params'][t][reg]), math.log10(f['alpha'][t]), res['chi_sq'][t], f['chi_sq'][t]))
-        assert np.all(np.isfinite(res['Coeffs'][t])) and np.isfinite(res['chi_sq'][t])
-    # record 0: same bracket as the reference (chi^2 = 0.9 * 550 at alpha ~ 1e-28.93); record 1 is decided by
-    # whether min chi^2 over alpha dips below 495 (reference: 496.04 at alpha = 1e-42, i.e. by noise) - see
-    # tools/exp_chi2table.py and DESIGN.md "Parity at the default order".
-    assert abs(res['chi_sq'][0] - f['chi_sq'][0]) <= 1e-3 * f['chi_sq'][0]
-    assert abs(math.log10(res['reg_params'][0][reg]) - math.log10(f['alpha'][0])) <= 0.01
-
-
 def test_solver_fallback_outside_the_in_lds_range():
     """N = 200 does not fit the in-LDS Jacobi kernel (161 KB > 160 KB LDS): vi_solve_trunc_f64 falls back to
     rocSOLVER syevd on the rescaled system - same truncation semantics, with and without pinv."""
@@ -323,12 +292,12 @@ def test_gcv_on_gpu_matches_reference(tmp_path):
         assert abs(got - v) <= 1e-6 * abs(v), (a, got, v)
     res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
     for t in range(2):
-        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-4
-        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 1e-4
-        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-4 * f['chi_sq'][t]
-    assert abs(math.log10(it.gcv(A, f['value'][0], W, regm, reg)) - math.log10(f['alpha'][0])) <= 1e-4
+        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-5
+        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 1e-5
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-5 * f['chi_sq'][t]
+    assert abs(math.log10(it.gcv(A, f['value'][0], W, regm, reg)) - math.log10(f['alpha'][0])) <= 1e-5
     assert abs(math.log10(it.find_reg_param(A, f['value'][0], W, regm, method='gcv')[reg])
-               - math.log10(f['alpha'][0])) <= 1e-4
+               - math.log10(f['alpha'][0])) <= 1e-5
 
 
 def test_full_batch_uses_walk_warm_start_and_keeps_parity(tmp_path):
