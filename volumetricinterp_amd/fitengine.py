@@ -326,11 +326,12 @@ class FitEngine(object):
         return out
 
     def default_prefetch(self):
-        # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound),
-        # a few steps ahead for large batches (the launch is already full; don't waste solves).  Beyond the in-LDS
-        # solver (N > 180: rocSOLVER, ~0.15 s per N = 1152 system) every extra solve is dear: stay close to the walk.
-        if not self.warm_enabled() and self.N > 180:
-            return 4
+        # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound), a few steps
+        # ahead for large batches (the launch is already full; don't waste solves).  Also beyond the in-LDS solver
+        # (N > 180, rocSOLVER syevd): its batched form costs 10.6 ms per system in launches of 4 but 2.7 ms in launches of
+        # 64 or more - one syevd at N = 1152 is ~900 small dependent kernels, and only a batch fills the GPU - so a
+        # single N = 1152 record takes 481 ms with the whole walk in one launch against 1164 ms four values at a time
+        # (measured; running several syevd calls from concurrent host threads instead made it slower, 1460 ms).
         return int(max(8, min(102, 2048 // max(1, self.T))))
 
     def default_multisection(self):
