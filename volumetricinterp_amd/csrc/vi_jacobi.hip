@@ -100,16 +100,16 @@ __device__ __forceinline__ int ring_next(int s, int m)
 __device__ __forceinline__ int slot_next(int s, int M) { return 2 * ring_next(s >> 1, M) + (s & 1); }
 
 // 1 / sqrt(x) for x in a safe range (no denormals, no overflow: the systems are scaled to max|X| in [1, 2) and rotated
-// elements exceed the absolute floor): hardware estimate v_rsq_f64 + two Newton steps, ~9 dependent operations instead
-// of the ~25 of the library sqrt / rsqrt (which also handle scaling and special values).  The rotation set-up is a chain
-// of dependent fp64 operations in ONE wave while the others wait at the barrier: it was 2700 of the 5600 cycles of a round.
+// elements exceed the absolute floor): hardware estimate v_rsq_f64 (measured 2^-24.2, tools/microbench/
+// rsq_f64_precision.hip) + ONE third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2 (remaining error ~e^3/3 = 5e-23):
+// 6 dependent operations instead of the ~25 of the library sqrt / rsqrt, which also handle scaling and special values
+// (two Newton steps would be 9; one alone leaves 4e-15).  The rotation set-up is a chain of dependent fp64 operations
+// in ONE wave while the others wait at the barrier: it was 2700 of the 5600 cycles of a round.
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-x * y, y, 1.0);
-    return fma(0.5 * y, e, y);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y, e * fma(0.375, e, 0.5), y);
 }
 
 // plane rotation of the pair (p, q): returns true and (c, s), the new diagonal entries, when the pair is to be rotated.
