@@ -279,7 +279,9 @@ struct WaveReplay {
 // rotation set-up - a chain of ~60 dependent fp64 operations in the first M lanes of wave 0 while the other waves wait
 // at the barrier - and 1500-2400 the block updates (128 fp64 operations and 16 + 16 LDS accesses per thread, three waves
 // per SIMD).  The set-up was 2700 cycles with library sqrt / division and the two rotations of an inner round under
-// separate branches; it is now division-free and branch-free (rot_params, rot_stage).  Two ways of taking it off the
+// separate branches; it is now division-free and branch-free (rot_params, rot_stage).  (Skipping the chain and the block
+// arithmetic in rounds where no pair rotates - most rounds of the late sweeps - was measured too: the extra control flow
+// cost registers (16 spilled) and the kernel ran 163 us per sweep instead of 150.)  Two ways of taking it off the
 // critical path were built and measured, and both lost: computing the next round's rotations one round ahead in a
 // dedicated wave (the diagonal blocks assembled from registers of the designated super-blocks: 170-260 us per sweep
 // against 154, the extra state spilled to scratch under the 168-register budget of three waves per SIMD), and letting
