@@ -1,6 +1,7 @@
 """Oracle (test infrastructure / CPU baseline only): the "optimised CPU" variant of BASELINE.md section 4.
 
-Same results as ``oracle.fit`` (same calls into LAPACK on the same matrices, same Brent iteration), with the two
+Same alpha and coefficients as ``oracle.fit``, bit for bit (same calls into LAPACK on the same matrices, same
+contractions inside chi^2, same Brent iteration; the covariance product uses matmul and agrees to rounding), with the two
 redundancies of the reference (volumetricinterp/interpolate.py:180-214, :255, :456) removed: A^T W A and A^T W b are
 formed once per record instead of once per trial alpha, and chi^2(alpha) is memoised, so the bracket walk is not
 repeated for every scale factor.  Reported beside the faithful variant for context; never a parity yardstick.
@@ -25,7 +26,7 @@ def fit_record(A, b, W, R, counter=None):
             C = np.squeeze(scipy.linalg.lstsq(AWA + np.power(10., a) * R, y)[0])
             if counter is not None:
                 counter[0] += 1
-            memo[a] = sum((A @ C - b)**2 * W)
+            memo[a] = sum((np.einsum('ji,i->j', A, C) - b)**2 * W)        # the reference's own contraction
         return memo[a]
 
     npts = len(b)

@@ -195,3 +195,25 @@ def test_grad_basis_matches_reference(tag):
     assert G.shape == Gref.shape == (len(g[tag + '_lat']), 3, m.nbasis)
     for c in range(3):
         assert np.max(colnorm_err(G[:, c, :], Gref[:, c, :])) <= 1e-13
+
+
+def test_optimised_cpu_variant_equals_the_faithful_one():
+    """oracle.fit_fast (A^T W A once per record, chi^2 memoised - the 'optimised CPU' baseline of BASELINE.md section 4)
+    makes the same LAPACK calls on the same matrices as the faithful restatement: identical alpha and coefficients."""
+    import warnings
+    import oracle
+    from oracle import fit_fast
+    f = load_golden('fit_k8l2')
+    o = oracle.SphHarmLagOracle(maxk=8, maxl=2)
+    A = o.basis(f['lat'], f['lon'], f['alt'])
+    b, W = f['value'][0], f['error'][0]**-2.
+    n_fast, n_slow = [0], [0]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        C, dC, c2, al = fit_fast.fit_record(A, b, W, f['R'], n_fast)
+        Cs, dCs, c2s, ps = oracle.fit_records(o, f['lat'], f['lon'], f['alt'], f['value'][:1], f['error'][:1],
+                                              {'curvature': f['R']}, ['curvature'], n_slow)
+    assert al == ps[0]['curvature'] and np.array_equal(C, Cs[0])
+    assert abs(c2 - c2s[0]) <= 1e-12 * c2s[0]
+    assert np.linalg.norm(dC - dCs[0]) <= 1e-10 * np.linalg.norm(dCs[0])
+    assert n_fast[0] < n_slow[0] // 2

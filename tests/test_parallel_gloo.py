@@ -157,3 +157,22 @@ def test_sharded_calc_coeffs_equals_single_process(tmp_path, world):
     for k in ('Coeffs', 'Covariance', 'chi_sq', 'time', 'alpha'):
         np.testing.assert_array_equal(outs[world][k], outs[1][k])
     assert int(outs[world]['omega_calls']) == 1
+
+
+def test_control_plane_framing_and_private_directory(tmp_path, monkeypatch):
+    """Wire format of the socket control plane (no pickle): frames and arrays survive a round trip; the rendezvous
+    directory is private to the user and a foreign or group-writable one is refused."""
+    import stat
+    from volumetricinterp_amd import parallel as P
+    parts = [b'', b'abc', bytes(range(256)) * 3]
+    assert P._unpack_parts(P._pack_parts(parts)) == parts
+    a = np.arange(24, dtype=np.float64).reshape(2, 3, 4) * 0.5
+    b = P._unpack_array(P._pack_array(a))
+    assert b.shape == a.shape and np.array_equal(a, b)
+    assert P._unpack_array(P._pack_array(np.zeros((0, 5)))).shape == (0, 5)
+    monkeypatch.delenv('XDG_RUNTIME_DIR', raising=False)
+    d = P._private_socket_dir()
+    st = os.lstat(d)
+    assert st.st_uid == os.getuid() and not (st.st_mode & 0o077) and stat.S_ISDIR(st.st_mode)
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path))
+    assert P._private_socket_dir() == str(tmp_path)
