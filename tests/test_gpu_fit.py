@@ -300,10 +300,13 @@ def test_gcv_on_gpu_matches_reference(tmp_path):
                - math.log10(f['alpha'][0])) <= 1e-5
 
 
-def test_full_batch_uses_walk_warm_start_and_keeps_parity(tmp_path):
-    """With >= 32 records the far tail of the bracket walk (alpha <= 1e-31) is solved in each record's
-    alpha -> 0 eigenbasis.  40 records = 10 copies of the screened golden records (record 1 brackets in
-    [-31, -30], i.e. on a walk value that now comes from the warm path): same parity gates as L7."""
+@pytest.mark.parametrize('shared', ['1', '0'])
+def test_full_batch_walk_paths_keep_parity(tmp_path, monkeypatch, shared):
+    """Batches solve the bracket walk in the shared bases of the batch (one reference decomposition per decade, bracket
+    ends again from cold solves); with that switched off, >= 32 records solve the far tail (alpha <= 1e-31) in each
+    record's alpha -> 0 eigenbasis.  40 records = 10 copies of the screened golden records (record 1 brackets in
+    [-31, -30]): same parity gates as L7 on both paths."""
+    monkeypatch.setenv('VINTERP_SHAREDWALK', shared)
     f = load_golden('fit_k8l2')
     regm, reg = reg_of(f)
     it = make_interp(tmp_path, str(f['cfg']))
@@ -311,7 +314,12 @@ def test_full_batch_uses_walk_warm_start_and_keeps_parity(tmp_path):
     value = np.tile(f['value'], (reps, 1))
     error = np.tile(f['error'], (reps, 1))
     res = it.fit_records(f['lat'], f['lon'], f['alt'], value, error, regm)
-    assert it.fit_stats.get('warm_solves', 0) > 40 * 60          # the walk tail really went through the warm path
+    if shared == '1':
+        assert it.fit_stats.get('shared_solves', 0) > 40 * 30        # the walk really went through the shared bases ...
+        assert 0 < it.fit_stats.get('reference_solves', 0) <= 102    # ... of one reference system per decade
+    else:
+        assert it.fit_stats.get('shared_solves', 0) == 0
+        assert it.fit_stats.get('warm_solves', 0) > 40 * 20          # the walk tail really went through the warm path
     T0 = f['value'].shape[0]
     for i in range(reps * T0):
         t = i % T0

@@ -128,20 +128,54 @@ def multisection_gen(xa, xb, fa, fb, K, xtol=MS_XTOL):
     return lo - flo * (hi - lo) / (fhi - flo), rounds, funcalls
 
 
-def chi2_search_gen(npts, multisection=0):
+class Exact(tuple):
+    """A request for chi^2 at these log10(alpha) from the evaluator's reference-grade path (see chi2_search_gen)."""
+    __slots__ = ()
+
+
+# |chi^2 - nu| <= this fraction of nu at a walk point: the sign is not taken from an approximate walk value
+WALK_SIGN_MARGIN = 1e-3
+
+
+def chi2_search_gen(npts, multisection=0, refine=False):
     """Coroutine form of Interpolate.chi2 (interpolate.py:152-218) for one record.
 
     Yields log10(alpha) (or a tuple of them), receives chi^2 at that alpha (or a list).  Returns
     (outcome, alpha, info) with outcome in {'too_smooth', 'no_root', 'root'}; alpha is 0, NaN or 10**root as
     in the reference.  multisection = K > 0: try the guarded K-point multisection first (see multisection_gen),
-    falling back to the Brent iteration when the bracket is not provably single-rooted."""
-    memo = {}
+    falling back to the Brent iteration when the bracket is not provably single-rooted.
+
+    refine: the evaluator serves the bracket walk from a cheaper path whose chi^2 carries noise (the shared bases of
+    FitEngine, ~1e-5 relative next to the poles of chi^2) and can serve ``Exact`` requests from its reference-grade one.
+    The walk only decides SIGNS, so its values are used as they come unless one lies within WALK_SIGN_MARGIN of nu; the two
+    ends of the bracket, whose values seed Brent's first steps, are always asked for again as Exact - the root finder
+    then sees the same numbers as without the cheaper path.  refine = 'all': every walk value is an Exact request (the
+    fallback when the refined ends contradict the walk)."""
+    memo, memo_x = {}, {}
 
     def f_at(a):                       # sub-generator: memoised chi^2(a)
         if a not in memo:
             memo[a] = yield a
         return memo[a]
 
+    def x_at(a):
+        if a not in memo_x:
+            memo_x[a] = (yield Exact((a,)))[0]
+        return memo_x[a]
+
+    def walk_at(a, nu):
+        if refine == 'all':
+            return (yield from x_at(a))
+        c = yield from f_at(a)
+        if refine and not abs(c - nu) > WALK_SIGN_MARGIN * nu:
+            c = yield from x_at(a)
+        return c
+
+    if refine == 'all':
+        # the whole table in one request (a walk of single requests would cost one evaluator round per decade)
+        table = tuple(float(-k) for k in range(0, 102))
+        for a, c in zip(table, (yield Exact(table))):
+            memo_x[a] = c
     bracket = False
     alpha = alpha0 = 0.
     val = val0 = 1.
@@ -150,7 +184,7 @@ def chi2_search_gen(npts, multisection=0):
     for sf in SCALE_FACTORS:
         nu = npts * sf
         alpha0, val0, alpha = 0., 1., 0.
-        val = (yield from f_at(alpha)) - nu
+        val = (yield from walk_at(alpha, nu)) - nu
         if val < 0:
             return 'too_smooth', 0, dict(sf=sf)
         while val0 * val > 0:
@@ -158,7 +192,7 @@ def chi2_search_gen(npts, multisection=0):
             val0 = val
             alpha0 = alpha
             alpha = alpha - 1.
-            val = (yield from f_at(alpha)) - nu
+            val = (yield from walk_at(alpha, nu)) - nu
             if alpha < -100.:
                 bracket = False
                 break
@@ -167,6 +201,19 @@ def chi2_search_gen(npts, multisection=0):
             break
     if not bracket:
         return 'no_root', float('nan'), dict(sf=None)
+    if refine and refine != 'all':
+        need = [a for a in (alpha, alpha0) if a not in memo_x]
+        if need:
+            for a, c in zip(need, (yield Exact(tuple(need)))):
+                memo_x[a] = c
+        va, vb = memo_x[alpha] - nu, memo_x[alpha0] - nu
+        if not va * vb <= 0:
+            # the reference-grade values do not bracket a sign change where the walk saw one: redo this record's walk on them
+            out = yield from chi2_search_gen(npts, multisection=multisection, refine='all')
+            out[2]['walk_redone_exact'] = True
+            return out
+        val, val0 = va, vb
+        memo[alpha], memo[alpha0] = memo_x[alpha], memo_x[alpha0]       # Brent re-evaluates its ends through f_at
     found = None
     other_end = None
     if multisection:
@@ -194,23 +241,25 @@ def chi2_search_gen(npts, multisection=0):
                                                      iterations=iters, finder=finder, other_end=other_end)
 
 
-def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
+def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False):
     """Drive one search coroutine per record against a batched chi^2 evaluator.
 
     npts_list[i]: number of finite data points of record i (``len(b)``, interpolate.py:175), or None to
-    skip the record (result NaN).  chi2_batch(rec_idx: int array, log10_alpha: float array) -> chi^2 array.
+    skip the record (result NaN).  chi2_batch(rec_idx: int array, log10_alpha: float array) -> chi^2 array; with
+    refine (see chi2_search_gen) it is also called as chi2_batch(rec, log10_alpha, exact: bool array).
     Returns (alpha list, outcome list, info list, number of chi^2 evaluations).
     """
     T = len(npts_list)
     gens, pending = {}, {}
     cache = [dict() for _ in range(T)]
+    cache_x = [dict() for _ in range(T)]
     results = [(None, float('nan'), {})] * T
     nevals = 0
     for i, n in enumerate(npts_list):
         if n is None:
             results[i] = ('skipped', float('nan'), {})
             continue
-        g = chi2_search_gen(n, multisection=multisection)
+        g = chi2_search_gen(n, multisection=multisection, refine=refine)
         gens[i] = g
         pending[i] = next(g)
 
@@ -229,22 +278,27 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
             for i in list(pending):
                 a = pending[i]
                 if isinstance(a, tuple):
-                    if all(x in cache[i] for x in a):
-                        advance(i, [cache[i][x] for x in a])
+                    ci = cache_x[i] if isinstance(a, Exact) else cache[i]
+                    if all(x in ci for x in a):
+                        advance(i, [ci[x] for x in a])
                         progressed = True
                 elif a in cache[i]:
                     advance(i, cache[i][a])
                     progressed = True
         if not gens:
             break
-        rec, alp = [], []
+        rec, alp, exact = [], [], []
         for i, a in pending.items():
             if isinstance(a, tuple):
+                ex = isinstance(a, Exact)
+                ci = cache_x[i] if ex else cache[i]
                 for x in a:
-                    if x not in cache[i]:
+                    if x not in ci:
                         rec.append(i)
                         alp.append(x)
+                        exact.append(ex)
                 continue
+            exact.append(False)
             rec.append(i)
             alp.append(a)
             # walk prefetch: integer alphas continue downwards; harmless extra evaluations
@@ -254,10 +308,15 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0):
                     if ak >= -101. and ak not in cache[i]:
                         rec.append(i)
                         alp.append(ak)
-        vals = chi2_batch(np.asarray(rec, dtype=np.int32), np.asarray(alp, dtype=np.float64))
+                        exact.append(False)
+        if any(exact):
+            vals = chi2_batch(np.asarray(rec, dtype=np.int32), np.asarray(alp, dtype=np.float64),
+                              np.asarray(exact, dtype=bool))
+        else:
+            vals = chi2_batch(np.asarray(rec, dtype=np.int32), np.asarray(alp, dtype=np.float64))
         nevals += len(rec)
-        for i, a, v in zip(rec, alp, vals):
-            cache[i][a] = float(v)
+        for i, a, v, ex in zip(rec, alp, vals, exact):
+            (cache_x[i] if ex else cache[i])[a] = float(v)
     return ([r[1] for r in results], [r[0] for r in results], [r[2] for r in results], nevals)
 
 
@@ -282,4 +341,109 @@ def run_brent_batched(brackets, f_batch):
             except StopIteration as stop:
                 out[i] = (stop.value[0], stop.value[1], stop.value[3])
                 del gens[i], pending[i]
+    return out
+
+
+POLISH_XTOL = 1e-7            # decades: a sign change confined to less than this without |f| getting small is a jump
+POLISH_BRENT_ROUNDS = 6
+
+
+def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, brent_rounds=POLISH_BRENT_ROUNDS,
+                       lanes=256):
+    """Root polishing of the consistency guard (FitEngine._search_and_finalize): small brackets around an approximate
+    root, an expensive f (cold solves), few records.  brackets = {rec: (xa, xb, fa, fb)}, f_batch(rec, x) -> f,
+    ftol = {rec: |f| below which the record is done}, target = {rec: x} the point whose nearest sign change is wanted.
+
+    Unlike the search proper this is not a restatement of the reference's brentq call: alpha is only meaningful to ~1e-6
+    decades here (the noise of chi^2 next to the poles and jumps the guard deals with), so a record stops as soon as
+    |f| <= ftol - a root for the guard's purposes - or its sign change is confined to xtol decades without |f| ever
+    getting there: a jump of f (an eigenvalue of X(alpha) crossing the truncation threshold), where bisecting on to
+    brentq's 2e-12 would cost 20 more rounds of one cold solve each for nothing.  Rounds are what costs (every one is a
+    launch that lasts as long as one cold solve): Brent's steps for all records first (superlinear on the smooth ones),
+    then, for the few left, K-section with as many points per record as fit in one launch of `lanes` systems.
+    Returns {rec: (root, rounds, other_end, how)}, how in {'ftol', 'jump', 'xtol'}."""
+    out = {}
+    state = {}                              # rec -> [lo, hi, flo, fhi, best_x, best_f]
+    gens, pending = {}, {}
+    rounds = 0
+
+    def note(i, x, f):
+        st = state[i]
+        if math.isnan(f):
+            return
+        if abs(f) < abs(st[5]):
+            st[4], st[5] = x, f
+        if st[0] < x < st[1]:
+            if _signbit(f) == _signbit(st[2]):
+                st[0], st[2] = x, f
+            else:
+                st[1], st[3] = x, f
+
+    def finished(i):
+        st = state[i]
+        if abs(st[5]) <= ftol[i]:
+            out[i] = (st[4], rounds, st[1] if st[4] == st[0] else st[0], 'ftol')
+        elif st[1] - st[0] <= xtol:
+            lo_best = abs(st[2]) <= abs(st[3])
+            out[i] = (st[0] if lo_best else st[1], rounds, st[1] if lo_best else st[0], 'jump')
+        else:
+            return False
+        return True
+
+    for i, (xa, xb, fa, fb) in brackets.items():
+        lo, hi, flo, fhi = (xa, xb, fa, fb) if xa < xb else (xb, xa, fb, fa)
+        state[i] = [lo, hi, flo, fhi, lo if abs(flo) <= abs(fhi) else hi, min(abs(flo), abs(fhi))]
+        if finished(i):
+            continue
+        g = brentq_gen(xa, xb, fa=fa, fb=fb)
+        try:
+            pending[i] = next(g)
+            gens[i] = g
+        except StopIteration as stop:
+            out[i] = (stop.value[0], 0, stop.value[3], 'xtol')
+    while gens and rounds < brent_rounds:
+        rec = np.array(sorted(gens), dtype=np.int32)
+        xs = np.array([pending[int(i)] for i in rec], dtype=np.float64)
+        vals = f_batch(rec, xs)
+        rounds += 1
+        for i, x, v in zip(rec.tolist(), xs.tolist(), vals):
+            note(i, x, float(v))
+            if finished(i):
+                del gens[i], pending[i]
+                continue
+            try:
+                pending[i] = gens[i].send(float(v))
+            except StopIteration as stop:
+                out[i] = (stop.value[0], rounds, stop.value[3], 'xtol')
+                del gens[i], pending[i]
+    left = sorted(gens)
+    while left:
+        K = max(3, min(255, lanes // len(left) - 1))
+        rec, xs = [], []
+        for i in left:
+            lo, hi = state[i][0], state[i][1]
+            for k in range(K):
+                rec.append(i)
+                xs.append(lo + (hi - lo) * (k + 1) / (K + 1))
+        vals = f_batch(np.asarray(rec, dtype=np.int32), np.asarray(xs, dtype=np.float64))
+        rounds += 1
+        for n, i in enumerate(left):
+            st = state[i]
+            pts = [(st[0], st[2])] + [(xs[n * K + k], float(vals[n * K + k])) for k in range(K)] + [(st[1], st[3])]
+            pts = [p for p in pts if not math.isnan(p[1])]
+            for x, f in pts:
+                if abs(f) < abs(st[5]):
+                    st[4], st[5] = x, f
+            tgt = target[i] if target is not None and i in target else st[4]
+            best = None
+            for (xa, fa), (xb, fb) in zip(pts[:-1], pts[1:]):
+                if _signbit(fa) != _signbit(fb):
+                    d = min(abs(xa - tgt), abs(xb - tgt)) if not (xa <= tgt <= xb) else 0.
+                    if best is None or d < best[0]:
+                        best = (d, xa, xb, fa, fb)
+            if best is not None:
+                st[0], st[1], st[2], st[3] = best[1:]
+            else:                               # cannot happen with finite end values of opposite sign; do not loop
+                st[1] = st[0]
+        left = [i for i in left if not finished(i)]
     return out

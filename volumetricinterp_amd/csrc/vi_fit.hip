@@ -177,14 +177,17 @@ __global__ __launch_bounds__(BS) void k_scale_system(int NN, double* __restrict_
 // power of two that brings max|X| into [1, 2).  The elements stay in registers between the max reduction and the
 // store (NN <= EPT * BS), so D1 and D2 are read once and X is written once (a single-record root-finder iterate spent
 // 45 us in the two separate kernels against ~1 ms in the solve).
+// slot1 / slot2: where D1 / D2 of system i live (slot1 null: D1[i], then X may be D1 itself - every element is read and
+// written by the same thread).
 template <int BS, int EPT>
-__global__ __launch_bounds__(BS) void k_form_pair_scaled(int NN, const double* __restrict__ D1, const double* __restrict__ D2,
-                                                         const int* __restrict__ slot, const double* __restrict__ alpha,
-                                                         double* __restrict__ X, double* __restrict__ scl)
+__global__ __launch_bounds__(BS) void k_form_pair_scaled(int NN, const double* D1, const double* __restrict__ D2,
+                                                         const int* __restrict__ slot1, const int* __restrict__ slot2,
+                                                         const double* __restrict__ alpha, double* X, double* __restrict__ scl)
 {
     __shared__ double red[BS / 64];
     const int64_t i = blockIdx.x;
-    const int64_t w = slot[i];
+    const int64_t w1 = slot1 ? slot1[i] : i;
+    const int64_t w = slot2[i];
     const double a = alpha[i];
     const int tid = threadIdx.x;
     double v[EPT];
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(BS) void k_form_pair_scaled(int NN, const double* _
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int e = tid + u * BS;
-        v[u] = e < NN ? fma(a, D2[w * NN + e], D1[w * NN + e]) : 0.0;
+        v[u] = e < NN ? fma(a, D2[w * NN + e], D1[w1 * NN + e]) : 0.0;
         mx = fmax(mx, fabs(v[u]));
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -687,7 +690,7 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
         if (NN <= 24 * 1024) {
             hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, d_D1, d_D2,
-                               d_slot + i0, d_alpha + i0, X, scl);
+                               d_slot + i0, d_slot + i0, d_alpha + i0, X, scl);
         } else {
             hipLaunchKernelGGL(k_form_pair, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_D1, d_D2, d_slot + i0,
                                d_alpha + i0, X);
@@ -699,6 +702,128 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_slot + i0, cp, d_C + i0 * N);
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
+namespace {
+// out[t] = min over the elements with R != 0 of (eps / 4) |AWA[t]| / |R|
+template <int BS>
+__global__ __launch_bounds__(BS) void k_reg_floor(int NN, const double* __restrict__ AWA, const double* __restrict__ R,
+                                                  double* __restrict__ out)
+{
+    __shared__ double red[BS / 64];
+    const double* Xt = AWA + (int64_t)blockIdx.x * NN;
+    double mn = 1.7976931348623157e308;
+    for (int e = threadIdx.x; e < NN; e += BS) {
+        const double r = fabs(R[e]);
+        if (r > 0.0) mn = fmin(mn, (0.25 * 2.220446049250313e-16) * fabs(Xt[e]) / r);
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < BS / 64; ++q) mn = fmin(mn, red[q]);
+        out[blockIdx.x] = mn;
+    }
+}
+}  // namespace
+
+// Below which alpha does the regularisation term vanish from X(alpha) = AWA + alpha R in floating point?  For
+// alpha |R_ij| < (eps / 4) |AWA_ij| in every element, fl(AWA_ij + alpha R_ij) = AWA_ij (the term is under half an ulp), so
+// all the systems of the bracket walk below that alpha are the SAME matrix bit for bit - in the reference as well, whose
+// LAPACK calls then return the same numbers again and again - and need one solve, not one per decade.
+extern "C" int vi_reg_floor_f64(vi_ctx* c, int64_t T, int32_t N, const double* d_AWA, const double* d_R, double* d_out)
+{
+    VI_REQUIRE(c && d_AWA && d_R && d_out, "null argument");
+    VI_REQUIRE(T >= 0 && N > 0, "bad size");
+    if (T == 0) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_reg_floor<256>, dim3((unsigned)T), dim3(256), 0, c->stream, N * N, d_AWA, d_R, d_out);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+namespace {
+// pointer arrays of the two batched products of vi_basis_solve_f64
+__global__ void k_basis_ptrs(int64_t B, int NN, const double* AWA, const int* __restrict__ rec, const double* V,
+                             const int* __restrict__ basis, double* T1, double* D1, const double** pA, const double** pV,
+                             double** pT, double** pD)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    pA[i] = AWA + (int64_t)rec[i] * NN;
+    pV[i] = V + (int64_t)basis[i] * NN;
+    pT[i] = T1 + i * NN;
+    pD[i] = D1 + i * NN;
+}
+}  // namespace
+
+// The bracket walk in SHARED bases.  The records of one geometry differ in their weights, not in their basis functions
+// or their regularisation matrix, so their walk systems X_j(alpha_k) = AWA_j + alpha_k R resemble each other decade by
+// decade: in the eigenbasis V_k of ONE reference system of the decade (mean weights of the batch; set up with
+// vi_warm_prepare_f64, which also gives D2_k = V_k^T R V_k) the system of every other record is nearly diagonal and
+// the Jacobi iteration needs 1-4 sweeps instead of 8 (alpha >= 1e-22) or 19-24 (below) - measured on the BASELINE
+// configs[2] geometry, tools/exp_shared_basis.py: 1349 -> 197 sweeps over 28 decades x 3 records.  For B (record, basis,
+// alpha) triples: D1 = V^T AWA V (two batched rocBLAS products, 8 N^3 flop), (D1 + alpha D2) c' = V^T y, C = V c'.
+// Any orthonormal V gives the same solution in exact arithmetic - a poor reference costs sweeps, not correctness.
+extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const double* d_y,
+                                  const int32_t* d_rec, const int32_t* d_basis, const double* d_alpha, const double* d_V,
+                                  const double* d_D2, double rcond, double* d_C, int32_t* d_rank)
+{
+    VI_REQUIRE(c && d_AWA && d_y && d_rec && d_basis && d_alpha && d_V && d_D2 && d_C, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    if (!vi_jacobi_supported(N)) {
+        vi_set_error("vi_basis_solve_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+    const size_t per = logb + sizeof(double) + (size_t)2 * NN * sizeof(double) + (size_t)2 * N * sizeof(double) + 4 * sizeof(void*);
+    int64_t Bc = (int64_t)(((size_t)8 << 30) / per);
+    if (Bc > 256) Bc &= ~(int64_t)255;            // whole rounds of the 256 CUs
+    if (Bc < 1) Bc = 1;
+    if (Bc > B) Bc = B;
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)Bc * per + 1024, &ws);
+    if (rc != VI_OK) return rc;
+    char* wp = (char*)ws + (size_t)Bc * logb;
+    double* scl = (double*)wp;
+    double* T1 = scl + Bc;
+    double* D1 = T1 + (size_t)Bc * NN;            // D1, then the scaled system in place
+    double* yt = D1 + (size_t)Bc * NN;
+    double* cp = yt + (size_t)Bc * N;
+    const double** pA = (const double**)(cp + (size_t)Bc * N);
+    const double** pV = pA + Bc;
+    double** pT = (double**)(pV + Bc);
+    double** pD = pT + Bc;
+    const double one = 1.0, zero = 0.0;
+    for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+        hipLaunchKernelGGL(k_basis_ptrs, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, c->stream, bc, NN, d_AWA,
+                           d_rec + i0, d_V, d_basis + i0, T1, D1, pA, pV, pT, pD);
+        VI_HIP(hipGetLastError());
+        VI_ROCBLAS(rocblas_dgemm_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, pA, N,
+                                         pV, N, &zero, pT, N, (rocblas_int)bc));
+        VI_ROCBLAS(rocblas_dgemm_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one, pV, N,
+                                         (const double* const*)pT, N, &zero, pD, N, (rocblas_int)bc));
+        hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, d_V, d_basis + i0, d_y, d_rec + i0, yt);
+        if (NN <= 24 * 1024) {
+            hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, D1, d_D2,
+                               (const int*)nullptr, d_basis + i0, d_alpha + i0, D1, scl);
+        } else {
+            vi_set_error("vi_basis_solve_f64: N=%d too large for the fused system kernel", N);
+            return VI_ERR_UNSUPPORTED;
+        }
+        VI_HIP(hipGetLastError());
+        rc = vi_jacobi_solve(c, bc, N, D1, scl, yt, nullptr, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
+                             JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
+        if (rc != VI_OK) return rc;
+        hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
+                           d_basis + i0, cp, d_C + i0 * N);
         VI_HIP(hipGetLastError());
     }
     return VI_OK;

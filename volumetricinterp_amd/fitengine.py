@@ -37,13 +37,16 @@ _lib._sig('vi_warm_prepare_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib
           _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_basis_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_reg_floor_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_chi2_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.c_int32, C.c_double, C.c_double, _lib.VOIDP, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.POINTER(C.c_double))
 _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, C.c_double, _lib.VOIDP)
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -64,6 +67,9 @@ class FitEngine(object):
             self.R[name] = ctx.to_device(M)
         self._bufs = {}
         self.T = 0
+        self._ref_rec = None
+        self._same_below = {}
+        self._walk_cache = {}
         self.stats = dict(solves=0, launches=0)
 
     @classmethod
@@ -94,12 +100,21 @@ class FitEngine(object):
         if W.shape != b.shape or W.ndim != 2 or W.shape[1] != self.P:
             raise ValueError('W, b must both be (T, %d)' % self.P)
         self.T = T = W.shape[0]
-        self.dW = self._buf('W', (T, self.P)).upload(W) if T else None
-        self.db = self._buf('b', (T, self.P)).upload(b) if T else None
+        self._ref_rec = None
+        if T and self.shared_walk_enabled():
+            # one extra 'record' T: the mean weights of the batch - the reference system whose eigenbases, decade by
+            # decade, the bracket walk of every record is solved in (chi2_batch_search)
+            W = np.concatenate([W, np.mean(W, axis=0, keepdims=True)])
+            b = np.concatenate([b, np.mean(b, axis=0, keepdims=True)])
+            self._ref_rec = T
+        self.dW = self._buf('W', W.shape).upload(W) if T else None
+        self.db = self._buf('b', b.shape).upload(b) if T else None
 
     def form_normal_equations(self):
         """A^T W A (T,N,N) and A^T W b (T,N) of the resident records - once per record, not per alpha."""
         T, N = self.T, self.N
+        if T and self._ref_rec is not None:
+            T += 1
         self.dAWA = self._buf('AWA', (T, N, N))
         self.dy = self._buf('y', (T, N))
         if T:
@@ -173,12 +188,39 @@ class FitEngine(object):
         # solve with eigenvectors per record, which only pays when the launch is full of records.
         return (self.warm_enabled() and self.T >= 32 and os.environ.get('VINTERP_WALKWARM', '1') != '0')
 
+    SHARED_WALK_MIN_RECORDS = 8
+
+    def shared_walk_enabled(self):
+        # Bracket walk in shared bases (vi_basis_solve_f64): per decade ONE cold decomposition of the reference system
+        # (mean weights of the batch) and then 1-4 sweeps per record instead of 8-24.  The reference costs as much as one
+        # more record and an extra launch in front of the first walk round, so it needs a few records to pay.
+        return (self.warm_enabled() and self.T >= self.SHARED_WALK_MIN_RECORDS and len(self.regularization_list) == 1
+                and os.environ.get('VINTERP_SHAREDWALK', '1') != '0')
+
     WALK_WARM_BELOW = -31.0          # log10(alpha) at and below which walk requests use the alpha -> 0 basis
     WALK_BASIS_ALPHA = 1e-60
+
+    def _find_same_below(self, name):
+        """Per record: the largest integer k with 10^k below the alpha at which alpha R drops out of AWA + alpha R to
+        rounding (vi_reg_floor_f64) - the walk systems of the decades under k are bit-identical to the one at k."""
+        T, N = self.T, self.N
+        if not T:
+            return
+        dfl = self._buf('regfloor', (T,))
+        _lib.check(_lib.lib.vi_reg_floor_f64(self.ctx.handle, T, N, self.dAWA.ptr, self.R[name].ptr, dfl.ptr),
+                   'vi_reg_floor_f64')
+        fl = np.empty(T)
+        _lib.check(_lib.lib.vi_d2h(self.ctx.handle, fl.ctypes.data_as(_lib.VOIDP), dfl.ptr, fl.nbytes), 'd2h')
+        k = np.full(T, -1000.)
+        ok = np.isfinite(fl) & (fl > 0) & (fl < 1e300)
+        k[ok] = np.ceil(np.log10(fl[ok])) - 1.
+        k[ok & ~(np.power(10., np.maximum(k, -300.)) < fl)] -= 1.
+        self._same_below[name] = k
 
     def _warm_reset(self):
         self._warm_slot = {}          # record -> slot of its Brent basis
         self._walk_slot = {}          # record -> slot of its alpha -> 0 (walk) basis
+        self._basis_slot = {}         # decade -> slot of the reference system's eigenbasis (shared walk)
 
     def _warm_buffers(self, tag):
         T, N = self.T, self.N
@@ -208,7 +250,50 @@ class FitEngine(object):
         _lib.check(_lib.lib.vi_warm_solve_f64(h, n, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, dslot.ptr, dalpha_ptr, EPS,
                                               dC_out, drank_out), 'vi_warm_solve_f64')
 
-    def chi2_batch_search(self, rec, log10a, name):
+    def chi2_batch_search(self, rec, log10a, name, exact=None):
+        """chi^2 requests of the search of `name`; see _chi2_batch_search_raw.  The bracket-walk requests (integer
+        log10 alpha) pass through a table first: decades below the record's floor (vi_reg_floor_f64) are one and the same
+        system bit for bit and are solved once, and a value once computed is not computed again - the search coroutines
+        memoise what they have asked for, but not that -60 and -61 are the same system."""
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        log10a = np.asarray(log10a, dtype=np.float64)
+        B = len(rec)
+        is_int = log10a == np.floor(log10a)
+        if not is_int.any() or os.environ.get('VINTERP_DEDUPE', '1') == '0':
+            return self._chi2_batch_search_raw(rec, log10a, name, exact)
+        ex = np.zeros(B, dtype=bool) if exact is None else np.asarray(exact, dtype=bool)
+        eff = log10a.copy()
+        kfl = self._same_below.get(name)
+        if kfl is not None:
+            low = is_int & (log10a < kfl[rec])
+            eff[low] = kfl[rec][low]
+        cache = self._walk_cache
+        out = np.empty(B)
+        todo, keys, dup, first_of = [], {}, [], {}
+        for j in np.nonzero(is_int)[0].tolist():
+            key = (int(rec[j]), int(eff[j]), bool(ex[j]))
+            v = cache.get(key)
+            if v is not None:
+                out[j] = v
+            elif key in first_of:
+                dup.append((j, first_of[key]))
+            else:
+                first_of[key] = j
+                keys[j] = key
+        hit = np.zeros(B, dtype=bool)
+        hit[[j for j in np.nonzero(is_int)[0].tolist() if j not in keys]] = True
+        todo = np.nonzero(~hit)[0]
+        self.stats['walk_same_system'] = self.stats.get('walk_same_system', 0) + int(hit.sum())
+        if len(todo):
+            vals = self._chi2_batch_search_raw(rec[todo], eff[todo], name, ex[todo] if exact is not None else None)
+            out[todo] = vals
+            for j, key in keys.items():
+                cache[key] = float(out[j])
+        for j, j0 in dup:
+            out[j] = out[j0]
+        return out
+
+    def _chi2_batch_search_raw(self, rec, log10a, name, exact=None):
         """chi^2 for the search of `name` (all other parameters zero), B requests.
 
         * integer log10(alpha) - the bracket walk - are solved cold, except (full launches only) the far tail
@@ -225,6 +310,8 @@ class FitEngine(object):
         is_int = log10a == np.floor(log10a)
         force = getattr(self, '_force_cold', None)
         forced = (np.array([int(r) in force for r in rec.tolist()], dtype=bool) if force else np.zeros(B, dtype=bool))
+        if exact is not None:
+            forced = forced | np.asarray(exact, dtype=bool)      # reference-grade requests of the search: cold solves
         if B == 1 and not is_int[0] and not forced[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot:
             # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
@@ -246,7 +333,9 @@ class FitEngine(object):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
-        walkwarm = (is_int & (log10a <= self.WALK_WARM_BELOW) & ~forced if self.walk_warm_enabled()
+        shared = (is_int & ~forced if (self._ref_rec is not None and self.shared_walk_enabled())
+                  else np.zeros(B, dtype=bool))
+        walkwarm = (is_int & (log10a <= self.WALK_WARM_BELOW) & ~forced & ~shared if self.walk_warm_enabled()
                     else np.zeros(B, dtype=bool))
         # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
         # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
@@ -273,9 +362,12 @@ class FitEngine(object):
             scratchR = self._buf('wp_scratchR', (len(recs_n),), np.int32)
             self._warm_prepare('w_', self._warm_slot, recs_n, [float(np.power(10., need[r])) for r in recs_n], name,
                                scratchC.ptr, scratchR.ptr)
-        cold = (is_int & (~walkwarm)) | forced           # forced: records whose search is being redone cold
-        order = np.concatenate([np.nonzero(cold)[0], np.nonzero(walkwarm)[0], np.nonzero(prep)[0], np.nonzero(warm)[0]])
-        nc, nww, npre, nw = int(cold.sum()), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
+        cold = (is_int & ~walkwarm & ~shared) | forced   # forced: records whose search is being redone cold
+        sh_idx = np.nonzero(shared)[0]
+        sh_idx = sh_idx[np.argsort(log10a[sh_idx], kind='stable')]          # by decade: one basis after the other
+        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(walkwarm)[0], np.nonzero(prep)[0],
+                                np.nonzero(warm)[0]])
+        nc, nsh, nww, npre, nw = int(cold.sum()), len(sh_idx), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
@@ -292,6 +384,35 @@ class FitEngine(object):
                                                        dCall.offset_ptr(s0 * N), drank.offset_ptr(s0), N * EPS, None),
                            'vi_solve_trunc_f64')
         o = nc
+        if nsh:
+            decades = np.rint(log10a[sh_idx]).astype(np.int64)
+            new_k = sorted(set(decades.tolist()) - set(self._basis_slot), reverse=True)
+            dV, dD1, dD2, dyt = (self._buf('sb_V', (102, N, N)), self._buf('sb_D1', (102, N, N)),
+                                 self._buf('sb_D2', (102, N, N)), self._buf('sb_yt', (102, N)))
+            if new_k:
+                if len(self._basis_slot) + len(new_k) > 102:
+                    raise RuntimeError('shared walk: more than 102 decades requested')
+                slot0 = len(self._basis_slot)
+                for i, k in enumerate(new_k):
+                    self._basis_slot[k] = slot0 + i
+                n = len(new_k)
+                dr = self._buf('sb_prec', (n,), np.int32).upload(np.full(n, self._ref_rec, dtype=np.int32))
+                da = self._buf('sb_palpha', (n,)).upload(np.power(10., np.asarray(new_k, dtype=np.float64)))
+                scratchC = self._buf('sb_scratchC', (n, N))
+                scratchR = self._buf('sb_scratchR', (n,), np.int32)
+                _lib.check(_lib.lib.vi_warm_prepare_f64(h, n, N, self.dAWA.ptr, dr.ptr, da.ptr, self.R[name].ptr,
+                                                        self.dy.ptr, EPS, scratchC.ptr, scratchR.ptr,
+                                                        dV.offset_ptr(slot0 * N * N), dD1.offset_ptr(slot0 * N * N),
+                                                        dD2.offset_ptr(slot0 * N * N), dyt.offset_ptr(slot0 * N)),
+                           'vi_warm_prepare_f64')
+                self.stats['solves'] += n
+                self.stats['reference_solves'] = self.stats.get('reference_solves', 0) + n
+            dbs = self._buf('sb_slot', (nsh,), np.int32).upload(
+                np.array([self._basis_slot[k] for k in decades.tolist()], dtype=np.int32))
+            _lib.check(_lib.lib.vi_basis_solve_f64(h, nsh, N, self.dAWA.ptr, self.dy.ptr, drec.offset_ptr(o),
+                                                   dbs.ptr, dal.offset_ptr(o), dV.ptr, dD2.ptr, EPS,
+                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_basis_solve_f64')
+            o += nsh
         if nww:
             recs = rec_o[o:o + nww]
             need = sorted(set(int(r) for r in recs.tolist() if int(r) not in self._walk_slot))
@@ -318,11 +439,12 @@ class FitEngine(object):
         out = np.empty(B)
         out[order] = tmp
         if trace:
-            print('[search round] B=%d cold=%d walk-warm=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
-                  (B, nc, nww, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            print('[search round] B=%d cold=%d shared=%d walk-warm=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, nsh, nww, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
         self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nww
+        self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
 
     def default_prefetch(self):
@@ -376,11 +498,16 @@ class FitEngine(object):
         infos = {}
         for name in self.regularization_list:
             self._warm_reset()
+            self._find_same_below(name)
+            self._walk_cache = {}
 
-            def evaluate(rec, log10a, _name=name):
-                return self.chi2_batch_search(rec, log10a, _name)
+            def evaluate(rec, log10a, exact=None, _name=name):
+                return self.chi2_batch_search(rec, log10a, _name, exact)
+            # walk values from the shared bases only decide signs; the bracket ends Brent starts from are asked for
+            # again from cold solves (alpha_search.chi2_search_gen, refine)
+            refine = bool(self._ref_rec is not None and self.shared_walk_enabled() and not cold)
             alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
-                                                                   multisection=multisection)
+                                                                   multisection=multisection, refine=refine)
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
@@ -536,7 +663,8 @@ class FitEngine(object):
             # next to the poles of chi^2(alpha) that the indefinite curvature matrix produces, the rotated system is not
             # accurate enough).  The warm root is still close to a root of the cold function: look for a sign change of the
             # COLD chi^2 - nu within 1e-4 .. 1e-1 decades of it (one batch of 8 cold solves per record) and run Brent on
-            # that small bracket with cold solves (6-8 iterations instead of the 20-40 of a search over the unit bracket).
+            # that small bracket with cold solves (alpha_search.run_polish_batched: ~10 rounds instead of the 20-40 of a search
+            # over the unit bracket to brentq's xtol).
             deltas = np.array([-1e-1, -1e-2, -1e-3, -1e-4, 1e-4, 1e-3, 1e-2, 1e-1])
             rec = np.repeat(np.asarray(bad, dtype=np.int32), len(deltas))
             roots = np.array([inf['info'][t]['log10_alpha'] for t in bad])
@@ -561,13 +689,16 @@ class FitEngine(object):
 
                 def f_batch(r, x):
                     return self.chi2_batch(r, {name: np.power(10., x)}) - np.array([nus[int(t)] for t in r])
-                sol = alpha_search.run_brent_batched(brackets, f_batch)
+                # stop at |chi^2 - nu| <= CONSISTENCY_TOL nu, or when the sign change is confined to 1e-7 decades (a jump):
+                # every round is a launch as long as one cold solve, and alpha means nothing beyond ~1e-6 decades here
+                sol = alpha_search.run_polish_batched(brackets, f_batch, {t: self.CONSISTENCY_TOL * nus[t] for t in brackets},
+                                                      target={t: float(roots[bad.index(t)]) for t in brackets})
                 done = sorted(sol)
                 for t in done:
-                    root, iters, oe = sol[t]
+                    root, iters, oe, how = sol[t]
                     params[t][name] = float(np.power(10., root))
-                    inf['info'][t].update(log10_alpha=root, other_end=oe, polished_cold=True,
-                                          polish_iterations=iters, warm_log10_alpha=float(roots[bad.index(t)]))
+                    inf['info'][t].update(log10_alpha=root, other_end=oe, polished_cold=True, polish_iterations=iters,
+                                          polish_end=how, warm_log10_alpha=float(roots[bad.index(t)]))
                 C2, V2, c2, r2 = self.finalize(params, calccov=calccov, only=set(done))
                 for t in done:
                     Coeffs[t], chi[t], ranks[t] = C2[t], c2[t], r2[t]
