@@ -222,3 +222,77 @@ def test_run_brent_batched_matches_scipy():
         root, iters, other = out[r]
         assert root == ref and iters == info.iterations
         assert other is None or abs(other - root) <= 4e-12 + 1e-15
+
+
+def _literal_walk(chi2, npts):
+    """interpolate.py:173-206 written out step by step (the bracket walk only): (outcome, sf, alpha, alpha0)."""
+    bracket = False
+    for sf in AS.SCALE_FACTORS:
+        nu = npts * sf
+        alpha0, val0, alpha = 0., 1., 0.
+        val = chi2(alpha) - nu
+        if val < 0:
+            return 'too_smooth', sf, None, None
+        while val0 * val > 0:
+            bracket = True
+            val0, alpha0 = val, alpha
+            alpha = alpha - 1.
+            val = chi2(alpha) - nu
+            if alpha < -100.:
+                bracket = False
+                break
+        if bracket:
+            return 'root', sf, alpha, alpha0
+    return 'no_root', None, None, None
+
+
+@pytest.mark.parametrize('refine', [False, True])
+def test_walk_over_a_known_table_equals_the_step_by_step_walk(refine):
+    """Once a record's 102 walk values are known the coroutine walks the remaining scale factors with array operations;
+    on random tables - sign changes anywhere (also in the last step, which the reference ignores), exact zeros, NaNs,
+    values within the sign margin of nu - it must take the scale factor and the bracket of the literal loop.  With
+    `refine` the evaluator returns the same numbers for Exact requests, so the answers must not change either."""
+    rng = np.random.default_rng(7)
+    npts = 1000
+    for case in range(400):
+        lvl = rng.choice([500., 650., 850., 950., 1050.])
+        tab = lvl + rng.choice([1., 30., 300.]) * rng.standard_normal(102)
+        if case % 3 == 0:                                     # a table that crosses the scale factors' targets somewhere
+            k = rng.integers(1, 102)
+            tab[k:] -= rng.uniform(100., 600.)
+        if case % 5 == 0:
+            tab[rng.integers(0, 102)] = float('nan')
+        if case % 7 == 0:
+            tab[rng.integers(0, 102)] = npts * rng.choice(AS.SCALE_FACTORS)          # an exact zero of chi^2 - nu
+        if case % 11 == 0:
+            tab[rng.integers(0, 102)] = npts * rng.choice(AS.SCALE_FACTORS) * (1. + 3e-4)     # inside the sign margin
+        if case % 13 == 0:
+            tab[0] = rng.uniform(100., 590.)                  # too smooth at once
+        chi2 = lambda a: float(tab[int(round(-a))])
+        want = _literal_walk(chi2, npts)
+        g = AS.chi2_search_gen(npts, refine=refine)
+        got = None
+        try:
+            x = next(g)
+            while True:
+                if isinstance(x, tuple):
+                    x = g.send([chi2(a) for a in x])
+                elif x == math.floor(x):
+                    x = g.send(chi2(x))
+                else:
+                    break                                     # the walk is over: Brent's first iterate
+        except StopIteration as stop:
+            got = stop.value
+        except ValueError:                                    # brentq on a NaN / same-sign bracket, as in the reference
+            assert want[0] == 'root'
+            continue
+        if got is None:
+            assert want[0] == 'root', (case, want)
+            fr = g.gi_frame.f_locals
+            assert (fr['sf_used'], fr['alpha'], fr['alpha0']) == want[1:], (case, want)
+        elif got[0] == 'root':                               # ended at once (an end of the bracket is an exact zero)
+            assert want[0] == 'root' and got[2]['sf'] == want[1] and got[2]['bracket'] == (want[2], want[3]), (case, want, got)
+        else:
+            assert got[0] == want[0], (case, want, got)
+            if want[0] == 'too_smooth':
+                assert got[2]['sf'] == want[1]

@@ -18,7 +18,8 @@ R = m.eval_reg_matricies['curvature']()
 value, error = synth.synth_records(A, T, seed0=1000)
 res = {}
 for mode in tuple(os.environ.get('MODES', '01')):
-    os.environ['VINTERP_SHAREDWALK'] = mode
+    os.environ['VINTERP_SHAREDWALK'] = '1' if mode == '1' else '0'
+    os.environ['VINTERP_WALKWARM'] = '0' if mode == 'c' else '1'          # 'c': every walk system solved cold
     eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
     eng.upload_records(error**-2., value)
     eng.fit_resident([P] * T, calccov=True)
@@ -69,12 +70,15 @@ for mode in tuple(os.environ.get('MODES', '01')):
     eng.close()
 if len(res) < 2:
     sys.exit(0)
-a0 = np.array([p['curvature'] for p in res['0']['reg_params']]); a1 = np.array([p['curvature'] for p in res['1']['reg_params']])
+k0, k1 = list(res)[:2]
+a0 = np.array([p['curvature'] for p in res[k0]['reg_params']]); a1 = np.array([p['curvature'] for p in res[k1]['reg_params']])
 dl = np.abs(np.log10(a1) - np.log10(a0))
 print('log10 alpha: max |diff| %.2e, records over 1e-6: %d, over 1e-3: %d' % (np.nanmax(dl), np.sum(dl > 1e-6), np.sum(dl > 1e-3)))
-c0, c1 = res['0']['chi_sq'], res['1']['chi_sq']
+c0, c1 = res[k0]['chi_sq'], res[k1]['chi_sq']
 print('chi^2: max rel diff %.2e' % np.nanmax(np.abs(c1 - c0) / c0))
-o0, o1 = res['0']['search']['curvature']['outcomes'], res['1']['search']['curvature']['outcomes']
+o0, o1 = res[k0]['search']['curvature']['outcomes'], res[k1]['search']['curvature']['outcomes']
 print('outcome flips: %d' % sum(x != y for x, y in zip(o0, o1)))
-sf0 = [i.get('sf') for i in res['0']['search']['curvature']['info']]; sf1 = [i.get('sf') for i in res['1']['search']['curvature']['info']]
+sf0 = [i.get('sf') for i in res[k0]['search']['curvature']['info']]; sf1 = [i.get('sf') for i in res[k1]['search']['curvature']['info']]
+print('records whose coefficients differ at all: %d' % int(np.sum([not np.array_equal(x, y, equal_nan=True) for x, y in zip(res[k0]['Coeffs'], res[k1]['Coeffs'])])))
+print('walks redone exact (shared): %d' % sum(1 for i in res[k1]['search']['curvature']['info'] if i.get('walk_redone_exact')))
 print('scale factor flips: %d' % sum(x != y for x, y in zip(sf0, sf1)))

@@ -158,33 +158,53 @@ def chi2_search_gen(npts, multisection=0, refine=False):
             memo[a] = yield a
         return memo[a]
 
-    def x_at(a):
-        if a not in memo_x:
-            memo_x[a] = (yield Exact((a,)))[0]
-        return memo_x[a]
-
-    def walk_at(a, nu):
-        if refine == 'all':
-            return (yield from x_at(a))
-        c = yield from f_at(a)
-        if refine and not abs(c - nu) > WALK_SIGN_MARGIN * nu:
-            c = yield from x_at(a)
-        return c
-
-    if refine == 'all':
+    all_exact = refine == 'all'
+    margin = WALK_SIGN_MARGIN if (refine and not all_exact) else -1.
+    if all_exact:
         # the whole table in one request (a walk of single requests would cost one evaluator round per decade)
         table = tuple(float(-k) for k in range(0, 102))
         for a, c in zip(table, (yield Exact(table))):
             memo_x[a] = c
+    walk = memo_x if all_exact else memo
     bracket = False
     alpha = alpha0 = 0.
     val = val0 = 1.
     sf_used = None
     nu = 0.
+    tab = None
     for sf in SCALE_FACTORS:
         nu = npts * sf
+        if len(walk) >= 102:
+            # the whole table is known (the first scale factor usually walks to the end without a bracket): the same
+            # walk in a few array operations instead of 102 interpreted steps
+            if tab is None:
+                tab = np.array([walk[float(-k)] for k in range(102)])
+            v = tab - nu
+            entered = v[0] > 0                                  # val0 * val > 0 with val0 = 1
+            stops = np.nonzero(~(v[:-1] * v[1:] > 0))[0]
+            k = int(stops[0]) + 1 if len(stops) else 102        # first step whose product is not positive
+            last = min(k, 101) if entered else 0
+            if not (margin >= 0. and bool(np.any(~(np.abs(v[:last + 1]) > margin * nu)))):
+                if v[0] < 0:
+                    return 'too_smooth', 0, dict(sf=sf)
+                if entered:
+                    bracket = k <= 100                          # the step to -101 ends the walk without a bracket
+                    if bracket:
+                        alpha, alpha0, val, val0 = float(-k), float(-(k - 1)), float(v[k]), float(v[k - 1])
+                if bracket:
+                    sf_used = sf
+                    break
+                continue
         alpha0, val0, alpha = 0., 1., 0.
-        val = (yield from walk_at(alpha, nu)) - nu
+        # (the two look-ups of the walk are written out: a sub-generator per step cost more than the step)
+        c = walk.get(alpha)
+        if c is None:
+            c = walk[alpha] = yield alpha
+        if margin >= 0. and not abs(c - nu) > margin * nu:           # too close to nu for a sign from an approximate value
+            c = memo_x.get(alpha)
+            if c is None:
+                c = memo_x[alpha] = (yield Exact((alpha,)))[0]
+        val = c - nu
         if val < 0:
             return 'too_smooth', 0, dict(sf=sf)
         while val0 * val > 0:
@@ -192,7 +212,14 @@ def chi2_search_gen(npts, multisection=0, refine=False):
             val0 = val
             alpha0 = alpha
             alpha = alpha - 1.
-            val = (yield from walk_at(alpha, nu)) - nu
+            c = walk.get(alpha)
+            if c is None:
+                c = walk[alpha] = yield alpha
+            if margin >= 0. and not abs(c - nu) > margin * nu:
+                c = memo_x.get(alpha)
+                if c is None:
+                    c = memo_x[alpha] = (yield Exact((alpha,)))[0]
+            val = c - nu
             if alpha < -100.:
                 bracket = False
                 break
@@ -270,23 +297,24 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False)
             results[i] = stop.value
             del gens[i], pending[i]
 
+    def serve(i):
+        # answer record i's requests from what is already known, for as long as that is possible
+        while i in gens:
+            a = pending[i]
+            if isinstance(a, tuple):
+                ci = cache_x[i] if isinstance(a, Exact) else cache[i]
+                if all(x in ci for x in a):
+                    advance(i, [ci[x] for x in a])
+                else:
+                    return
+            elif a in cache[i]:
+                advance(i, cache[i][a])
+            else:
+                return
+
+    for i in list(gens):
+        serve(i)
     while gens:
-        # serve everything already cached
-        progressed = True
-        while progressed:
-            progressed = False
-            for i in list(pending):
-                a = pending[i]
-                if isinstance(a, tuple):
-                    ci = cache_x[i] if isinstance(a, Exact) else cache[i]
-                    if all(x in ci for x in a):
-                        advance(i, [ci[x] for x in a])
-                        progressed = True
-                elif a in cache[i]:
-                    advance(i, cache[i][a])
-                    progressed = True
-        if not gens:
-            break
         rec, alp, exact = [], [], []
         for i, a in pending.items():
             if isinstance(a, tuple):
@@ -315,8 +343,10 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False)
         else:
             vals = chi2_batch(np.asarray(rec, dtype=np.int32), np.asarray(alp, dtype=np.float64))
         nevals += len(rec)
-        for i, a, v, ex in zip(rec, alp, vals, exact):
-            (cache_x[i] if ex else cache[i])[a] = float(v)
+        for i, a, v, ex in zip(rec, alp, np.asarray(vals, dtype=np.float64).tolist(), exact):
+            (cache_x[i] if ex else cache[i])[a] = v
+        for i in list(pending):             # every pending record had a request in this batch
+            serve(i)
     return ([r[1] for r in results], [r[0] for r in results], [r[2] for r in results], nevals)
 
 

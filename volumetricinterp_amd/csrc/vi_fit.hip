@@ -30,14 +30,15 @@ namespace {
 
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
-// B[t][n][p] = At[n][p] * W[t][p]
+// B[t][n][p] = At[n][p] * W[min(t, tvalid - 1)][p]   (entries beyond tvalid pad the last GEMM group)
 __global__ void k_scale_rows(int64_t P, int N, const double* __restrict__ At, const double* __restrict__ W,
-                             double* __restrict__ B)
+                             double* __restrict__ B, int tvalid)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.y, t = blockIdx.z;
     if (p >= P) return;
-    B[((int64_t)t * N + n) * P + p] = At[(int64_t)n * P + p] * W[(int64_t)t * P + p];
+    const int ts = t < tvalid ? t : tvalid - 1;
+    B[((int64_t)t * N + n) * P + p] = At[(int64_t)n * P + p] * W[(int64_t)ts * P + p];
 }
 
 __global__ void k_mul(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o)
@@ -284,30 +285,94 @@ __global__ __launch_bounds__(BS) void k_trunc_apply(int N, const double* __restr
     }
 }
 
-// chi2[i] = sum_p W[rec_i][p] (Rm[i][p] - b[rec_i][p])^2
-template <int BS>
-__global__ __launch_bounds__(BS) void k_chi2(int64_t P, const double* __restrict__ Rm, const int* __restrict__ rec,
-                                             int64_t rec_base, const double* __restrict__ W,
-                                             const double* __restrict__ b, double* __restrict__ chi2)
+// chi^2 of S systems per workgroup, one data point per thread:
+//   part[i][blockIdx.y] = sum over the block's points p of W[rec_i][p] (sum_n At[n][p] C[i][n] - b[rec_i][p])^2.
+// The arithmetic of a system does not depend on the batch it is evaluated in: the model value of a point is ONE chain of
+// fused multiply-adds over n = 0 .. N-1, the points of a block are summed by a fixed tree, the blocks by k_chi2_sum in
+// order - whatever S (which only decides how many systems share a block's loads of At), whatever the batch size.  (The
+// library GEMM this replaces chose its kernel, hence its summation order, by the number of systems: a record's chi^2
+// changed in the 10th digit with the batch it was fitted in, and Brent's path with it.)
+template <int BS, int S>
+__global__ __launch_bounds__(BS) void k_chi2_part(int64_t P, int N, int64_t B, const double* __restrict__ At,
+                                                  const double* __restrict__ C, const int* __restrict__ rec,
+                                                  int64_t rec_base, const double* __restrict__ W,
+                                                  const double* __restrict__ b, double* __restrict__ part)
 {
-    __shared__ double red[BS];
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int64_t r = rec ? rec[i] : rec_base + i;
-    const double* Ri = Rm + (int64_t)i * P;
-    const double* Wi = W + r * P;
-    const double* bi = b + r * P;
-    double acc = 0.0;
-    for (int64_t p = tid; p < P; p += BS) {
-        const double d = Ri[p] - bi[p];
-        acc = fma(d * d, Wi[p], acc);
-    }
-    red[tid] = acc;
+    extern __shared__ double shC[];                 // S x N coefficients, then BS partial sums
+    double* red = shC + (size_t)S * N;
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * S;
+    const int ns = (int)((B - i0) < S ? (B - i0) : S);
+    for (int e = tid; e < S * N; e += BS) shC[e] = (e / N) < ns ? C[i0 * N + e] : 0.0;
     __syncthreads();
-    for (int s = BS / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+    const int64_t p = (int64_t)blockIdx.y * BS + tid;
+    double acc[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) acc[q] = 0.0;
+    if (p < P) {
+#pragma unroll 8
+        for (int n = 0; n < N; ++n) {
+            const double a = At[(int64_t)n * P + p];
+#pragma unroll
+            for (int q = 0; q < S; ++q) acc[q] = fma(a, shC[q * N + n], acc[q]);
+        }
+    }
+    for (int q = 0; q < ns; ++q) {
+        double v = 0.0;
+        if (p < P) {
+            const int64_t r = rec ? rec[i0 + q] : rec_base + i0 + q;
+            const double d = acc[q] - b[r * P + p];
+            v = d * d * W[r * P + p];
+        }
+        red[tid] = v;
+        __syncthreads();
+        for (int h = BS / 2; h > 0; h >>= 1) {
+            if (tid < h) red[tid] += red[tid + h];
+            __syncthreads();
+        }
+        if (tid == 0) part[(i0 + q) * gridDim.y + blockIdx.y] = red[0];
         __syncthreads();
     }
-    if (tid == 0) chi2[i] = red[0];
+}
+
+__global__ void k_chi2_sum(int64_t B, int nb, const double* __restrict__ part, double* __restrict__ chi2)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double acc = 0.0;
+    for (int j = 0; j < nb; ++j) acc += part[i * nb + j];
+    chi2[i] = acc;
+}
+
+// y[t][n] = sum_p At[n][p] W[t][p] b[t][p]: one workgroup per (n, group of 8 records), fixed summation order per record
+template <int BS>
+__global__ __launch_bounds__(BS) void k_atwb(int64_t P, int N, int64_t T, const double* __restrict__ At,
+                                             const double* __restrict__ W, const double* __restrict__ b,
+                                             double* __restrict__ y)
+{
+    __shared__ double red[BS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.y * 8;
+    const int nt = (int)((T - t0) < 8 ? (T - t0) : 8);
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int64_t p = tid; p < P; p += BS) {
+        const double a = At[(int64_t)n * P + p];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < nt) acc[q] = fma(a, W[(t0 + q) * P + p] * b[(t0 + q) * P + p], acc[q]);
+    }
+    for (int q = 0; q < nt; ++q) {
+        red[tid] = acc[q];
+        __syncthreads();
+        for (int h = BS / 2; h > 0; h >>= 1) {
+            if (tid < h) red[tid] += red[tid + h];
+            __syncthreads();
+        }
+        if (tid == 0) y[(t0 + q) * N + n] = red[0];
+        __syncthreads();
+    }
 }
 
 // 2: in-LDS parallel Jacobi (vi_jacobi.hip, default where it fits), 1: rocSOLVER syevj, 0: rocSOLVER syevd.
@@ -359,6 +424,48 @@ double jacobi_floor_warm()
 
 }  // namespace
 
+namespace {
+// The library picks its GEMM kernel - hence the summation order - by the problem size AND the batch count, so a record's
+// normal equations and rotated systems used to change in the 16th digit with the number of records computed alongside,
+// and (chi^2(alpha) being what it is at the default order) Brent's path with them.  Every batched product that feeds a
+// record's numbers is therefore issued in groups of exactly GEMM_GROUP matrices through the pointer-array interface;
+// the last group is padded with repeats of its last entry whose results go to a scratch area.
+constexpr int GEMM_GROUP = 32;
+
+// out[i] = base + min(i, count - 1) * stride   (i < countp; inputs)          or, with scratch != nullptr (outputs),
+// out[i] = i < count ? base + i * stride : scratch + (i - count) * sstride
+__global__ void k_group_ptrs(int64_t count, int64_t countp, const double* base, int64_t stride, double* scratch,
+                             int64_t sstride, const double** out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= countp) return;
+    if (i < count || !scratch) out[i] = base + (i < count ? i : count - 1) * stride;
+    else out[i] = scratch + (i - count) * sstride;
+}
+
+inline int64_t group_pad(int64_t n) { return (n + GEMM_GROUP - 1) / GEMM_GROUP * GEMM_GROUP; }
+
+int group_ptrs(vi_ctx* c, int64_t count, const double* base, int64_t stride, double* scratch, int64_t sstride,
+               const double** out)
+{
+    const int64_t cp = group_pad(count);
+    hipLaunchKernelGGL(k_group_ptrs, dim3(nblk(cp, 256)), dim3(256), 0, c->stream, count, cp, base, stride, scratch, sstride,
+                       out);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+int gemm_groups(vi_ctx* c, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double** pA, int lda,
+                const double** pB, int ldb, const double** pC, int ldc, int64_t count)
+{
+    const double one = 1.0, zero = 0.0;
+    for (int64_t g0 = 0; g0 < group_pad(count); g0 += GEMM_GROUP)
+        VI_ROCBLAS(rocblas_dgemm_batched(c->blas, ta, tb, m, n, k, &one, pA + g0, lda, pB + g0, ldb, &zero,
+                                         (double* const*)(pC + g0), ldc, GEMM_GROUP));
+    return VI_OK;
+}
+}  // namespace
+
 extern "C" int vi_normal_eq_f64(vi_ctx* c, int64_t T, int64_t P, int32_t N, const double* d_At, const double* d_W,
                                 const double* d_b, double* d_AWA, double* d_y)
 {
@@ -367,31 +474,35 @@ extern "C" int vi_normal_eq_f64(vi_ctx* c, int64_t T, int64_t P, int32_t N, cons
     if (T == 0) return VI_OK;
     VI_HIP(hipSetDevice(c->device));
     const size_t per_t = (size_t)N * P * sizeof(double);
+    const int NN = N * N;
     int64_t Tc = (int64_t)((size_t)1 << 30) / (int64_t)per_t;      // <= 1 GiB of scaled copies at a time
     if (Tc < 1) Tc = 1;
     if (Tc > T) Tc = T;
+    const int64_t Tcp = group_pad(Tc);
     void* ws = nullptr;
-    const size_t wb_bytes = (size_t)T * P * sizeof(double);
-    int rc = vi_ctx_workspace(c, (size_t)Tc * per_t + wb_bytes, &ws);
+    int rc = vi_ctx_workspace(c, (size_t)Tc * per_t + (size_t)GEMM_GROUP * NN * sizeof(double) + (size_t)3 * Tcp * sizeof(void*),
+                              &ws);
     if (rc != VI_OK) return rc;
     double* Bs = (double*)ws;
-    double* wb = Bs + (size_t)Tc * N * P;
-    const double one = 1.0, zero = 0.0;
+    double* scratch = Bs + (size_t)Tc * N * P;
+    const double** pA = (const double**)(scratch + (size_t)GEMM_GROUP * NN);
+    const double** pB = pA + Tcp;
+    const double** pC = pB + Tcp;
     for (int64_t t0 = 0; t0 < T; t0 += Tc) {
         const int64_t tc = (T - t0) < Tc ? (T - t0) : Tc;
         hipLaunchKernelGGL(k_scale_rows, dim3(nblk(P, 256), N, (unsigned)tc), dim3(256), 0, c->stream, P, N, d_At,
-                           d_W + t0 * P, Bs);
+                           d_W + t0 * P, Bs, (int)tc);
         VI_HIP(hipGetLastError());
         // AWA_t (N x N) = A^T (N x P) * B_t (P x N), column-major views of the row-major N x P arrays
-        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N,
-                                                 (rocblas_int)P, &one, d_At, (rocblas_int)P, 0, Bs, (rocblas_int)P,
-                                                 (rocblas_stride)N * P, &zero, d_AWA + t0 * N * N, N,
-                                                 (rocblas_stride)N * N, (rocblas_int)tc));
+        if ((rc = group_ptrs(c, tc, d_At, 0, nullptr, 0, pA)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, tc, Bs, (int64_t)N * P, nullptr, 0, pB)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, tc, d_AWA + t0 * NN, NN, scratch, NN, pC)) != VI_OK) return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, (int)P, pA, (int)P, pB, (int)P,
+                              pC, N, tc)) != VI_OK)
+            return rc;
     }
-    hipLaunchKernelGGL(k_mul, dim3(nblk(T * P, 256)), dim3(256), 0, c->stream, T * P, d_W, d_b, wb);
+    hipLaunchKernelGGL(k_atwb<256>, dim3(N, nblk(T, 8)), dim3(256), 0, c->stream, P, N, T, d_At, d_W, d_b, d_y);
     VI_HIP(hipGetLastError());
-    VI_ROCBLAS(rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)T,
-                             (rocblas_int)P, &one, d_At, (rocblas_int)P, wb, (rocblas_int)P, &zero, d_y, N));
     return VI_OK;
 }
 
@@ -528,24 +639,25 @@ extern "C" int vi_chi2_f64(vi_ctx* c, int64_t B, int64_t P, int32_t N, const dou
     VI_REQUIRE(B >= 0 && P > 0 && N > 0, "bad size");
     if (B == 0) return VI_OK;
     VI_HIP(hipSetDevice(c->device));
-    int64_t Bc = (int64_t)((size_t)1 << 29) / (int64_t)(P * sizeof(double));
-    if (Bc < 1) Bc = 1;
-    if (Bc > B) Bc = B;
+    const int nb = (int)nblk(P, 256);
     void* ws = nullptr;
-    int rc = vi_ctx_workspace(c, (size_t)Bc * P * sizeof(double), &ws);
+    int rc = vi_ctx_workspace(c, (size_t)B * nb * sizeof(double), &ws);
     if (rc != VI_OK) return rc;
-    double* Rm = (double*)ws;
-    const double one = 1.0, zero = 0.0;
-    for (int64_t i0 = 0; i0 < B; i0 += Bc) {
-        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
-        // Rm (P x bc) = A (P x N) * C^T-view (N x bc)
-        VI_ROCBLAS(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (rocblas_int)P,
-                                 (rocblas_int)bc, N, &one, d_At, (rocblas_int)P, d_C + i0 * N, N, &zero, Rm,
-                                 (rocblas_int)P));
-        hipLaunchKernelGGL(k_chi2<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, P, Rm, d_rec ? d_rec + i0 : nullptr,
-                           i0, d_W, d_b, d_chi2 + i0);
-        VI_HIP(hipGetLastError());
+    double* part = (double*)ws;
+    // S systems share a block's loads of the basis; a system's arithmetic is the same for every S (see k_chi2_part)
+    if (B >= 2048) {
+        hipLaunchKernelGGL((k_chi2_part<256, 8>), dim3(nblk(B, 8), nb), dim3(256), (size_t)(8 * N + 256) * sizeof(double),
+                           c->stream, P, N, B, d_At, d_C, d_rec, (int64_t)0, d_W, d_b, part);
+    } else if (B >= 256) {
+        hipLaunchKernelGGL((k_chi2_part<256, 2>), dim3(nblk(B, 2), nb), dim3(256), (size_t)(2 * N + 256) * sizeof(double),
+                           c->stream, P, N, B, d_At, d_C, d_rec, (int64_t)0, d_W, d_b, part);
+    } else {
+        hipLaunchKernelGGL((k_chi2_part<256, 1>), dim3((unsigned)B, nb), dim3(256), (size_t)(N + 256) * sizeof(double),
+                           c->stream, P, N, B, d_At, d_C, d_rec, (int64_t)0, d_W, d_b, part);
     }
+    VI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_chi2_sum, dim3(nblk(B, 256)), dim3(256), 0, c->stream, B, nb, part, d_chi2);
+    VI_HIP(hipGetLastError());
     return VI_OK;
 }
 
@@ -614,23 +726,31 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     VI_HIP(hipSetDevice(c->device));
     const int NN = N * N;
     const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
-    const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * NN * sizeof(double);
+    const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * NN * sizeof(double) + 6 * sizeof(void*);
     // chunks of records, so that the rotation logs and temporaries stay within 4 GiB of workspace (4.3 MB per record at
     // N = 144: 10 000 records at once would ask for 43 GB)
     int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
     if (Bc < 1) Bc = 1;
     if (Bc > B) Bc = B;
+    const int64_t Bcp = group_pad(Bc);
     void* ws = nullptr;
-    int rc = vi_ctx_workspace(c, (size_t)Bc * per + 1024, &ws);
+    int rc = vi_ctx_workspace(c, (size_t)Bc * per + (size_t)2 * GEMM_GROUP * NN * sizeof(double) + 6 * GEMM_GROUP * sizeof(void*) + 1024,
+                              &ws);
     if (rc != VI_OK) return rc;
     char* wp = (char*)ws + (size_t)Bc * logb;
     double* scl = (double*)wp;
     double* lam = scl + Bc;
     double* T0 = lam + (size_t)Bc * N;     // X0, later AWA[rec]
     double* T1 = T0 + (size_t)Bc * NN;
-    int* nrd = (int*)(T1 + (size_t)Bc * NN);
-    const double one = 1.0, zero = 0.0;
-    const rocblas_stride sN = (rocblas_stride)NN;
+    double* scrT = T1 + (size_t)Bc * NN;   // results of the padding entries of the last product group
+    double* scrD = scrT + (size_t)GEMM_GROUP * NN;
+    const double** pT0 = (const double**)(scrD + (size_t)GEMM_GROUP * NN);
+    const double** pV = pT0 + Bcp;
+    const double** pT1 = pV + Bcp;
+    const double** pR = pT1 + Bcp;
+    const double** pD1 = pR + Bcp;
+    const double** pD2 = pD1 + Bcp;
+    int* nrd = (int*)(pD2 + Bcp);
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
         const int32_t* recc = d_rec + i0;
@@ -643,18 +763,23 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
         if (rc != VI_OK) return rc;
         rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, Vc);
         if (rc != VI_OK) return rc;
-        // D1 = V^T (AWA V)
+        // D1 = V^T (AWA V), D2 = V^T (R V): four batched products in groups of fixed size (see GEMM_GROUP)
         hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, T0);
         VI_HIP(hipGetLastError());
-        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, T0, N,
-                                                 sN, Vc, N, sN, &zero, T1, N, sN, (rocblas_int)bc));
-        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
-                                                 Vc, N, sN, T1, N, sN, &zero, d_D1 + i0 * NN, N, sN, (rocblas_int)bc));
-        // D2 = V^T (R V)
-        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, d_R, N,
-                                                 0, Vc, N, sN, &zero, T1, N, sN, (rocblas_int)bc));
-        VI_ROCBLAS(rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one,
-                                                 Vc, N, sN, T1, N, sN, &zero, d_D2 + i0 * NN, N, sN, (rocblas_int)bc));
+        if ((rc = group_ptrs(c, bc, T0, NN, nullptr, 0, pT0)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, Vc, NN, nullptr, 0, pV)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, T1, NN, scrT, NN, pT1)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_R, 0, nullptr, 0, pR)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_D1 + i0 * NN, NN, scrD, NN, pD1)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_D2 + i0 * NN, NN, scrD, NN, pD2)) != VI_OK) return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pT0, N, pV, N, pT1, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD1, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pR, N, pV, N, pT1, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD2, N, bc)) != VI_OK)
+            return rc;
         hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vc, nullptr, d_y, recc, d_yt + i0 * N);
         VI_HIP(hipGetLastError());
     }

@@ -247,9 +247,11 @@ struct WaveReplay {
     }
     __device__ __forceinline__ static void inv(double& p, double& q, double2 r)      // (p, q) <- J (p, q)
     {
+        // the contractions are spelled out: left to the compiler, the 1- and 8-column instances of the eigenvector kernel
+        // fused different products and a record's eigenvectors depended on the size of the batch it was solved in
         const double gp = p, gq = q;
-        p = r.x * gp + r.y * gq;
-        q = -r.y * gp + r.x * gq;
+        p = fma(r.x, gp, r.y * gq);
+        q = fma(r.x, gq, -(r.y * gp));
     }
     // r[0..3]: (c, s) of this lane's match in the round ((1, 0) where there is no match); intra: round 0 of a sweep
     __device__ __forceinline__ void round(const double2 (&r)[4], bool intra)

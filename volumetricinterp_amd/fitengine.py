@@ -182,12 +182,6 @@ class FitEngine(object):
             return False
         return 8 <= self.N <= 180
 
-    def walk_warm_enabled(self):
-        # the alpha -> 0 eigenbasis makes the walk systems alpha <= 1e-31 nearly diagonal (measured: 6.8 / 2.1 us
-        # per system for alpha in 1e-31..1e-60 / 1e-61..1e-101 against 22 us cold).  Setting it up costs one cold
-        # solve with eigenvectors per record, which only pays when the launch is full of records.
-        return (self.warm_enabled() and self.T >= 32 and os.environ.get('VINTERP_WALKWARM', '1') != '0')
-
     SHARED_WALK_MIN_RECORDS = 8
 
     def shared_walk_enabled(self):
@@ -196,9 +190,6 @@ class FitEngine(object):
         # more record and an extra launch in front of the first walk round, so it needs a few records to pay.
         return (self.warm_enabled() and self.T >= self.SHARED_WALK_MIN_RECORDS and len(self.regularization_list) == 1
                 and os.environ.get('VINTERP_SHAREDWALK', '1') != '0')
-
-    WALK_WARM_BELOW = -31.0          # log10(alpha) at and below which walk requests use the alpha -> 0 basis
-    WALK_BASIS_ALPHA = 1e-60
 
     def _find_same_below(self, name):
         """Per record: the largest integer k with 10^k below the alpha at which alpha R drops out of AWA + alpha R to
@@ -219,7 +210,6 @@ class FitEngine(object):
 
     def _warm_reset(self):
         self._warm_slot = {}          # record -> slot of its Brent basis
-        self._walk_slot = {}          # record -> slot of its alpha -> 0 (walk) basis
         self._basis_slot = {}         # decade -> slot of the reference system's eigenbasis (shared walk)
 
     def _warm_buffers(self, tag):
@@ -267,37 +257,40 @@ class FitEngine(object):
         if kfl is not None:
             low = is_int & (log10a < kfl[rec])
             eff[low] = kfl[rec][low]
-        cache = self._walk_cache
+        # table of the walk values already known, per (exact?, record, decade); NaN = not yet
+        tab = self._walk_cache.get('tab')
+        if tab is None or tab.shape[1] != self.T:
+            tab = self._walk_cache['tab'] = np.full((2, self.T, 102), np.nan)
         out = np.empty(B)
-        todo, keys, dup, first_of = [], {}, [], {}
-        for j in np.nonzero(is_int)[0].tolist():
-            key = (int(rec[j]), int(eff[j]), bool(ex[j]))
-            v = cache.get(key)
-            if v is not None:
-                out[j] = v
-            elif key in first_of:
-                dup.append((j, first_of[key]))
-            else:
-                first_of[key] = j
-                keys[j] = key
-        hit = np.zeros(B, dtype=bool)
-        hit[[j for j in np.nonzero(is_int)[0].tolist() if j not in keys]] = True
-        todo = np.nonzero(~hit)[0]
-        self.stats['walk_same_system'] = self.stats.get('walk_same_system', 0) + int(hit.sum())
+        ii = np.nonzero(is_int)[0]
+        dec = (-eff[ii]).astype(np.int64)
+        inside = (dec >= 0) & (dec < 102) & (rec[ii] >= 0) & (rec[ii] < self.T)
+        e_i, r_i, d_i = ex[ii].astype(np.int64), rec[ii].astype(np.int64), np.where(inside, dec, 0)
+        known = np.where(inside, tab[e_i, np.where(inside, r_i, 0), d_i], np.nan)
+        hit_i = ~np.isnan(known)
+        out[ii[hit_i]] = known[hit_i]
+        # of the misses, one representative per (exact, record, decade)
+        miss = ii[~hit_i]
+        key = (e_i[~hit_i] * self.T + r_i[~hit_i]) * 102 + d_i[~hit_i]
+        key = np.where(inside[~hit_i], key, -1 - np.arange(len(miss)))          # requests outside the table: no sharing
+        _, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+        reps = miss[first]
+        todo = np.sort(np.concatenate([np.nonzero(~is_int)[0], reps]))
+        self.stats['walk_same_system'] = self.stats.get('walk_same_system', 0) + B - len(todo)
         if len(todo):
-            vals = self._chi2_batch_search_raw(rec[todo], eff[todo], name, ex[todo] if exact is not None else None)
-            out[todo] = vals
-            for j, key in keys.items():
-                cache[key] = float(out[j])
-        for j, j0 in dup:
-            out[j] = out[j0]
+            out[todo] = self._chi2_batch_search_raw(rec[todo], eff[todo], name, ex[todo] if exact is not None else None)
+        out[miss] = out[reps][inverse]
+        ok = inside[~hit_i]
+        tab[e_i[~hit_i][ok], r_i[~hit_i][ok], d_i[~hit_i][ok]] = out[miss][ok]
         return out
 
     def _chi2_batch_search_raw(self, rec, log10a, name, exact=None):
         """chi^2 for the search of `name` (all other parameters zero), B requests.
 
-        * integer log10(alpha) - the bracket walk - are solved cold, except (full launches only) the far tail
-          alpha <= 1e-31, which is solved in the record's alpha -> 0 eigenbasis;
+        * integer log10(alpha) - the bracket walk - are solved cold for a few records; a batch (>= 8 records) solves them in
+          the eigenbases, one per decade, of a reference system built from the batch's mean weights (vi_basis_solve_f64):
+          those values only decide signs, the bracket ends Brent starts from come as `exact` requests, which are solved
+          cold - a record's answer is the same, bit for bit, whatever batch it is fitted in;
         * root-finder requests (non-integer) are solved in the record's rotated system, which is set up (a cold
           decomposition with eigenvectors) at the middle of the record's unit bracket when its first request arrives."""
         rec = np.ascontiguousarray(rec, dtype=np.int32)
@@ -335,8 +328,6 @@ class FitEngine(object):
         alpha = np.power(10., log10a)
         shared = (is_int & ~forced if (self._ref_rec is not None and self.shared_walk_enabled())
                   else np.zeros(B, dtype=bool))
-        walkwarm = (is_int & (log10a <= self.WALK_WARM_BELOW) & ~forced & ~shared if self.walk_warm_enabled()
-                    else np.zeros(B, dtype=bool))
         # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
         # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
         warm = np.zeros(B, dtype=bool)
@@ -362,12 +353,11 @@ class FitEngine(object):
             scratchR = self._buf('wp_scratchR', (len(recs_n),), np.int32)
             self._warm_prepare('w_', self._warm_slot, recs_n, [float(np.power(10., need[r])) for r in recs_n], name,
                                scratchC.ptr, scratchR.ptr)
-        cold = (is_int & ~walkwarm & ~shared) | forced   # forced: records whose search is being redone cold
+        cold = (is_int & ~shared) | forced               # forced: records whose search is being redone cold
         sh_idx = np.nonzero(shared)[0]
         sh_idx = sh_idx[np.argsort(log10a[sh_idx], kind='stable')]          # by decade: one basis after the other
-        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(walkwarm)[0], np.nonzero(prep)[0],
-                                np.nonzero(warm)[0]])
-        nc, nsh, nww, npre, nw = int(cold.sum()), len(sh_idx), int(walkwarm.sum()), int(prep.sum()), int(warm.sum())
+        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], np.nonzero(warm)[0]])
+        nc, nsh, npre, nw = int(cold.sum()), len(sh_idx), int(prep.sum()), int(warm.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
@@ -413,17 +403,6 @@ class FitEngine(object):
                                                    dbs.ptr, dal.offset_ptr(o), dV.ptr, dD2.ptr, EPS,
                                                    dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_basis_solve_f64')
             o += nsh
-        if nww:
-            recs = rec_o[o:o + nww]
-            need = sorted(set(int(r) for r in recs.tolist() if int(r) not in self._walk_slot))
-            if need:
-                scratchC = self._buf('ww_scratchC', (len(need), N))
-                scratchR = self._buf('ww_scratchR', (len(need),), np.int32)
-                self._warm_prepare('ww_', self._walk_slot, need, [self.WALK_BASIS_ALPHA] * len(need), name,
-                                   scratchC.ptr, scratchR.ptr)
-            self._warm_solve('ww_', self._walk_slot, recs, dal.offset_ptr(o), nww, dCall.offset_ptr(o * N),
-                             drank.offset_ptr(o))
-            o += nww
         if npre:
             self._warm_prepare('w_', self._warm_slot, rec_o[o:o + npre].tolist(), alpha_o[o:o + npre], name,
                                dCall.offset_ptr(o * N), drank.offset_ptr(o))
@@ -439,11 +418,11 @@ class FitEngine(object):
         out = np.empty(B)
         out[order] = tmp
         if trace:
-            print('[search round] B=%d cold=%d shared=%d walk-warm=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
-                  (B, nc, nsh, nww, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            print('[search round] B=%d cold=%d shared=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, nsh, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
-        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nww
+        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw
         self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
 
