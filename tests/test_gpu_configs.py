@@ -235,7 +235,9 @@ def test_c4_doubled_order_stages():
     C, rank = _solve(ctx, X[None], y[:1])
     ref = scipy.linalg.lstsq(X, y[0])[0]
     assert rank[0] == N
-    assert rel(C[0], ref) <= 1e-7
+    # north_star's tolerance; measured 0.9e-7 .. 1.1e-7 (rocSOLVER syevd at N = 1152, cond(X) ~ 1e7): it moves with the last
+    # bits of A^T W A, and the fitted values below are what the coefficients are for
+    assert rel(C[0], ref) <= 1e-6
     fit = A @ C[0]
     assert rel(fit, A @ ref) <= 1e-10
 
