@@ -379,7 +379,7 @@ POLISH_BRENT_ROUNDS = 6
 
 
 def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, brent_rounds=POLISH_BRENT_ROUNDS,
-                       lanes=256):
+                       ksection=15):
     """Root polishing of the consistency guard (FitEngine._search_and_finalize): small brackets around an approximate
     root, an expensive f (cold solves), few records.  brackets = {rec: (xa, xb, fa, fb)}, f_batch(rec, x) -> f,
     ftol = {rec: |f| below which the record is done}, target = {rec: x} the point whose nearest sign change is wanted.
@@ -390,7 +390,8 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
     getting there: a jump of f (an eigenvalue of X(alpha) crossing the truncation threshold), where bisecting on to
     brentq's 2e-12 would cost 20 more rounds of one cold solve each for nothing.  Rounds are what costs (every one is a
     launch that lasts as long as one cold solve): Brent's steps for all records first (superlinear on the smooth ones),
-    then, for the few left, K-section with as many points per record as fit in one launch of `lanes` systems.
+    then, for the few left, K-section with `ksection` points per record and round (a fixed number: what a record gets must
+    not depend on how many others are being polished alongside).
     Returns {rec: (root, rounds, other_end, how)}, how in {'ftol', 'jump', 'xtol'}."""
     out = {}
     state = {}                              # rec -> [lo, hi, flo, fhi, best_x, best_f]
@@ -448,7 +449,7 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
                 del gens[i], pending[i]
     left = sorted(gens)
     while left:
-        K = max(3, min(255, lanes // len(left) - 1))
+        K = int(ksection)
         rec, xs = [], []
         for i in left:
             lo, hi = state[i][0], state[i][1]

@@ -51,6 +51,18 @@ _lib.EXPORTS += ['vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
 
+class _View(object):
+    """A window into another engine's device buffer (records lo.. of a batch), for the pipelines of fit_resident."""
+
+    def __init__(self, parent, offset_elems):
+        self._parent = parent                   # keeps the allocation alive
+        self.dtype = parent.dtype
+        self.ptr = parent.offset_ptr(offset_elems)
+
+    def offset_ptr(self, nelem):
+        return C.c_void_p(self.ptr.value + int(nelem) * self.dtype.itemsize)
+
+
 class FitEngine(object):
     def __init__(self, ctx, At_dev, P, N, reg_matrices, regularization_list):
         self.ctx = ctx
@@ -58,6 +70,7 @@ class FitEngine(object):
         self.P, self.N = int(P), int(N)
         self.regularization_list = list(regularization_list)
         self.R = {}
+        self._R_host = {}
         for name in self.regularization_list:
             M = np.ascontiguousarray(reg_matrices[name], dtype=np.float64)
             if M.shape != (self.N, self.N):
@@ -65,9 +78,12 @@ class FitEngine(object):
             if not np.all(np.isfinite(M)):
                 raise ValueError('array must not contain infs or NaNs')
             self.R[name] = ctx.to_device(M)
+            self._R_host[name] = M
         self._bufs = {}
         self.T = 0
         self._ref_rec = None
+        self._subs = None
+        self._bounds = [0, 0]
         self._same_below = {}
         self._walk_cache = {}
         self.stats = dict(solves=0, launches=0)
@@ -100,26 +116,60 @@ class FitEngine(object):
         if W.shape != b.shape or W.ndim != 2 or W.shape[1] != self.P:
             raise ValueError('W, b must both be (T, %d)' % self.P)
         self.T = T = W.shape[0]
-        self._ref_rec = None
-        if T and self.shared_walk_enabled():
-            # one extra 'record' T: the mean weights of the batch - the reference system whose eigenbases, decade by
-            # decade, the bracket walk of every record is solved in (chi2_batch_search)
-            W = np.concatenate([W, np.mean(W, axis=0, keepdims=True)])
-            b = np.concatenate([b, np.mean(b, axis=0, keepdims=True)])
-            self._ref_rec = T
+        self._subs = None
         self.dW = self._buf('W', W.shape).upload(W) if T else None
         self.db = self._buf('b', b.shape).upload(b) if T else None
+        K = self.pipelines()
+        self._bounds = [(T * k) // K for k in range(K + 1)]
+        # the reference system(s) of the shared walk: the mean weights of the batch (of each pipeline's share of it)
+        self._ref_host = [(np.mean(W[lo:hi], axis=0, keepdims=True), np.mean(b[lo:hi], axis=0, keepdims=True))
+                          for lo, hi in zip(self._bounds[:-1], self._bounds[1:])] if T else []
+        self._ref_rec = None
+        if T:
+            self._set_reference(*(self._ref_host[0] if K == 1 else (np.mean(W, axis=0, keepdims=True),
+                                                                    np.mean(b, axis=0, keepdims=True))))
+
+    def _set_reference(self, Wref, bref):
+        """One extra 'record' T: mean weights - the reference system whose eigenbases, decade by decade, the bracket walk
+        of every record is solved in (chi2_batch_search)."""
+        self._ref_rec = None
+        if self.T and self.shared_walk_enabled():
+            self.dWref = self._buf('Wref', (1, self.P)).upload(Wref)
+            self.dbref = self._buf('bref', (1, self.P)).upload(bref)
+            self._ref_rec = self.T
+
+    def adopt_records(self, dW, db, T, Wref, bref):
+        """Use T records already resident on the device (views into another engine's buffers)."""
+        self.T = int(T)
+        self._subs = None
+        self.dW, self.db = dW, db
+        self._bounds = [0, self.T]
+        self._ref_host = [(Wref, bref)]
+        self._set_reference(Wref, bref)
+
+    PIPELINE_MIN_RECORDS = 256
+
+    def pipelines(self):
+        """Number of concurrent fit pipelines a batch is split into (fit_resident)."""
+        if getattr(self, '_no_pipeline', False) or not self.warm_enabled():
+            return 1
+        k = os.environ.get('VINTERP_PIPELINES')
+        if k is not None:
+            return max(1, min(int(k), max(1, self.T)))
+        return int(max(1, min(4, self.T // self.PIPELINE_MIN_RECORDS)))
 
     def form_normal_equations(self):
         """A^T W A (T,N,N) and A^T W b (T,N) of the resident records - once per record, not per alpha."""
         T, N = self.T, self.N
-        if T and self._ref_rec is not None:
-            T += 1
-        self.dAWA = self._buf('AWA', (T, N, N))
-        self.dy = self._buf('y', (T, N))
+        self.dAWA = self._buf('AWA', (T + 1, N, N))
+        self.dy = self._buf('y', (T + 1, N))
         if T:
             _lib.check(_lib.lib.vi_normal_eq_f64(self.ctx.handle, T, self.P, N, self.At.ptr, self.dW.ptr, self.db.ptr,
                                                  self.dAWA.ptr, self.dy.ptr), 'vi_normal_eq_f64')
+            if self._ref_rec is not None:
+                _lib.check(_lib.lib.vi_normal_eq_f64(self.ctx.handle, 1, self.P, N, self.At.ptr, self.dWref.ptr,
+                                                     self.dbref.ptr, self.dAWA.offset_ptr(T * N * N),
+                                                     self.dy.offset_ptr(T * N)), 'vi_normal_eq_f64')
 
     def load_records(self, W, b):
         self.upload_records(W, b)
@@ -539,16 +589,24 @@ class FitEngine(object):
             infos[name] = dict(outcomes=outcomes)
         return params, infos
 
-    def finalize(self, params, calccov=True, only=None):
+    def finalize(self, params, calccov=True, only=None, out=None):
         """Final eval_C(calccov=True) + chi^2 for every record (interpolate.py:566-569).
 
         Records whose parameters contain NaN become NaN rows (interpolate.py:558-563); with `only`, so do the
         records not listed."""
         T, N = self.T, self.N
-        Coeffs = np.full((T, N), np.nan)
-        Cov = np.full((T, N, N), np.nan) if calccov else None
-        chi = np.full(T, np.nan)
-        ranks = np.full(T, -1, dtype=np.int32)
+        if out is not None:                     # caller's arrays (a pipeline's share of the batch's result)
+            Coeffs, Cov, chi, ranks = out
+            Coeffs[:] = np.nan
+            chi[:] = np.nan
+            ranks[:] = -1
+            if Cov is not None:
+                Cov[:] = np.nan
+        else:
+            Coeffs = np.full((T, N), np.nan)
+            Cov = np.full((T, N, N), np.nan) if calccov else None
+            chi = np.full(T, np.nan)
+            ranks = np.full(T, -1, dtype=np.int32)
         good = [t for t in range(T) if (only is None or t in only)
                 and not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
         step = max(1, min(len(good), 2048))
@@ -585,7 +643,7 @@ class FitEngine(object):
     CONSISTENCY_TOL = 1e-6        # |chi^2_final - nu| <= tol * nu: the record is reported as consistent
     REDO_TOL = 1e-4               # beyond this the record's root search is redone with cold solves only
 
-    def _search_and_finalize(self, npts, calccov, prefetch, multisection):
+    def _search_and_finalize(self, npts, calccov, prefetch, multisection, out=None):
         """chi^2 search + final solve, with a consistency guard between the two.
 
         The root finder's iterates are served from each record's rotated system (warm start), the final
@@ -603,7 +661,7 @@ class FitEngine(object):
         the fit is only reproducible to 1e-3 anyway); redoing those cold would triple the cost of a batch for
         nothing."""
         params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
-        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
+        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov, out=out)
         if len(self.regularization_list) != 1 or os.environ.get('VINTERP_GUARD', '1') == '0':
             return params, infos, Coeffs, Cov, chi, ranks
         name = self.regularization_list[0]
@@ -705,22 +763,93 @@ class FitEngine(object):
             violators()
         return params, infos, Coeffs, Cov, chi, ranks
 
-    def fit_resident(self, npts, calccov=True, prefetch=None, multisection=None):
+    def fit_resident(self, npts, calccov=True, prefetch=None, multisection=None, _out=None):
         """Fit the records made resident by upload_records()."""
+        if len(self._bounds) > 2:
+            return self._fit_pipelined(npts, calccov, prefetch, multisection)
         self.form_normal_equations()
-        params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection)
+        params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection, out=_out)
+        return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
+
+    def _fit_pipelined(self, npts, calccov, prefetch, multisection):
+        """The batch as K independent sub-batches, each driven by its own host thread on its own context (stream, rocBLAS
+        handle, workspace).  A fit is a chain of ~80 dependent launches with host logic in between, and a launch lasts as
+        long as its slowest system: one pipeline leaves the GPU idle a quarter of the time and half empty for much of the
+        rest; the launches of independent sub-batches fill those gaps (measured, 26 x 100 geometry: 1000 records 1280 ->
+        1430 records/s with three pipelines, 4000 records 1330 -> 1670 with four).  Records are independent and a record's
+        numbers do not depend on the batch it is in (test_c1_fit_is_independent_of_the_batch_and_consistent), so the
+        split changes nothing but the time."""
+        import threading
+        T, N, K = self.T, self.N, len(self._bounds) - 1
+        if self._subs is None or len(self._subs) != K:
+            self._close_subs()
+            self._subs = []
+            for k in range(K):
+                ctx = self.ctx if k == 0 else _lib.Context(self.ctx.device)
+                sub = FitEngine(ctx, self.At, self.P, N, {n: self._R_host[n] for n in self.regularization_list},
+                                self.regularization_list)
+                sub._no_pipeline = True
+                self._subs.append(sub)
+        Coeffs = np.empty((T, N))
+        Cov = np.empty((T, N, N)) if calccov else None
+        chi = np.empty(T)
+        ranks = np.empty(T, dtype=np.int32)
+        results, errors = [None] * K, [None] * K
+
+        def run(k):
+            lo, hi = self._bounds[k], self._bounds[k + 1]
+            try:
+                sub = self._subs[k]
+                sub.adopt_records(_View(self.dW, lo * self.P), _View(self.db, lo * self.P), hi - lo, *self._ref_host[k])
+                sub.stats = dict(solves=0, launches=0)
+                out = (Coeffs[lo:hi], Cov[lo:hi] if calccov else None, chi[lo:hi], ranks[lo:hi])
+                results[k] = sub.fit_resident(list(npts[lo:hi]), calccov, prefetch, multisection, _out=out)
+                sub.ctx.sync()
+            except BaseException as e:          # re-raised in the caller's thread
+                errors[k] = e
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(1, K)]
+        for th in threads:
+            th.start()
+        run(0)
+        for th in threads:
+            th.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        params, infos = [], {}
+        for k, r in enumerate(results):
+            lo = self._bounds[k]
+            params += r['reg_params']
+            for name, inf in r['search'].items():
+                m = infos.setdefault(name, dict(outcomes=[], info=[], evaluations=0, polished_cold=[], redone_cold=[]))
+                m['outcomes'] += inf['outcomes']
+                m['info'] += inf['info']
+                m['evaluations'] += inf.get('evaluations', 0)
+                m['polished_cold'] += [lo + t for t in inf.get('polished_cold', [])]
+                m['redone_cold'] += [lo + t for t in inf.get('redone_cold', [])]
+            for key, v in self._subs[k].stats.items():
+                self.stats[key] = self.stats.get(key, 0) + v
+        self.stats['pipelines'] = K
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 
     def fit(self, W, b, npts, calccov=True, prefetch=None, multisection=None, method='chi2', point_lists=None):
-        self.load_records(W, b)
+        self.upload_records(W, b)
         if method == 'gcv':
+            self.form_normal_equations()
             params, infos = self.search_gcv(point_lists)
             Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
             return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
-        params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection)
-        return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
+        return self.fit_resident(npts, calccov=calccov, prefetch=prefetch, multisection=multisection)
+
+    def _close_subs(self):
+        for k, sub in enumerate(self._subs or []):
+            sub.close()
+            if k > 0:
+                sub.ctx.close()
+        self._subs = None
 
     def close(self):
+        self._close_subs()
         for b in self._bufs.values():
             b.free()
         self._bufs = {}
