@@ -205,6 +205,27 @@ int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, co
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
                        double rcond, double* d_C, int32_t* d_rank);
 
+/* The two phases of vi_warm_prepare_f64 as separate calls: vi_decompose_f64 forms and decomposes X(alpha0[i]) of B records
+ * (solution to d_C as vi_solve_trunc_f64 gives it) and leaves the rotation logs - vi_rotation_log_bytes(N) per system - and
+ * the rounds they hold in buffers of the caller; vi_warm_finish_f64 turns B consecutive logs into V, D1, D2, yt.  A record
+ * fitted alone decomposes the middle of every candidate bracket in the launch of its bracket walk and finishes only the one
+ * the walk points at. */
+size_t vi_rotation_log_bytes(int32_t N);
+int  vi_decompose_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
+                      const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,
+                      int32_t* d_rank, void* d_log, int32_t* d_nround);
+int  vi_warm_finish_f64(vi_ctx* ctx, int64_t B, int32_t N, const void* d_log, const int32_t* d_nround,
+                        const double* d_AWA, const int32_t* d_rec, const double* d_R, const double* d_y,
+                        double* d_V, double* d_D1, double* d_D2, double* d_yt);
+
+/* vi_warm_solve_f64 for B (slot, record, alpha) triples that also MOVES each slot's rotated system to alpha: the
+ * eigenvectors of the rotated system come out of the rotation log, V <- V Vw, and D1, D2, yt are formed again from the
+ * untransformed AWA[rec], R, y[rec].  Brent's late iterates (interpolate.py:214) sit within 1e-3 decades of each other;
+ * from a basis that close a warm solve takes 1-3 sweeps instead of 6-13.  A slot may appear once per call. */
+int  vi_warm_rebase_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const double* d_R, const double* d_y,
+                        const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
+                        double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank);
+
 /* out[t] = the alpha below which alpha R vanishes from AWA[t] + alpha R in floating point (alpha |R_ij| under a quarter
  * of eps |AWA_ij| in every element): the systems of the bracket walk (interpolate.py:186-203) below it are one and the
  * same matrix and are solved once. */

@@ -103,6 +103,32 @@ __global__ void k_v_vec(int N, const double* __restrict__ V, const int* __restri
     }
 }
 
+// dst[slot[i]] = src[i]   (NN elements each)
+__global__ void k_scatter_mat(int NN, const double* __restrict__ src, const int* __restrict__ slot, double* __restrict__ dst)
+{
+    const int64_t i = blockIdx.x;
+    const double* s = src + i * NN;
+    double* d = dst + (int64_t)slot[i] * NN;
+    for (int e = threadIdx.x; e < NN; e += blockDim.x) d[e] = s[e];
+}
+
+// out[slot[i]][k] = sum_r V[i][k*N + r] * v[rec[i]][r]     (k_vt_vec with the result scattered to the slots)
+__global__ void k_vt_vec_slot(int N, const double* __restrict__ V, const double* __restrict__ v, const int* __restrict__ rec,
+                              const int* __restrict__ slot, double* __restrict__ out)
+{
+    const int64_t i = blockIdx.x;
+    const double* Vi = V + i * N * N;
+    const double* vi = v + (int64_t)rec[i] * N;
+    double* o = out + (int64_t)slot[i] * N;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int k = wave; k < N; k += nw) {
+        double acc = 0.0;
+        for (int r = lane; r < N; r += 64) acc = fma(Vi[(int64_t)k * N + r], vi[r], acc);
+        for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_down(acc, o2);
+        if (lane == 0) o[k] = acc;
+    }
+}
+
 // Leave-one-out systems of generalised cross validation (interpolate.py:333-349): deleting data point p from a
 // record is a rank-one down-date of its normal equations,
 //   X_p = AWA - W_p a_p a_p^T + alpha R,   y_p = y - W_p b_p a_p,      a_p = column p of the N x P basis.
@@ -434,23 +460,28 @@ constexpr int GEMM_GROUP = 32;
 
 // out[i] = base + min(i, count - 1) * stride   (i < countp; inputs)          or, with scratch != nullptr (outputs),
 // out[i] = i < count ? base + i * stride : scratch + (i - count) * sstride
+// idx != nullptr: entry i lives at base + idx[i] * stride (records / slots picked out of a larger array)
 __global__ void k_group_ptrs(int64_t count, int64_t countp, const double* base, int64_t stride, double* scratch,
-                             int64_t sstride, const double** out)
+                             int64_t sstride, const double** out, const int* __restrict__ idx)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= countp) return;
-    if (i < count || !scratch) out[i] = base + (i < count ? i : count - 1) * stride;
-    else out[i] = scratch + (i - count) * sstride;
+    if (i < count || !scratch) {
+        const int64_t j = i < count ? i : count - 1;
+        out[i] = base + (idx ? (int64_t)idx[j] : j) * stride;
+    } else {
+        out[i] = scratch + (i - count) * sstride;
+    }
 }
 
 inline int64_t group_pad(int64_t n) { return (n + GEMM_GROUP - 1) / GEMM_GROUP * GEMM_GROUP; }
 
 int group_ptrs(vi_ctx* c, int64_t count, const double* base, int64_t stride, double* scratch, int64_t sstride,
-               const double** out)
+               const double** out, const int* idx = nullptr)
 {
     const int64_t cp = group_pad(count);
     hipLaunchKernelGGL(k_group_ptrs, dim3(nblk(cp, 256)), dim3(256), 0, c->stream, count, cp, base, stride, scratch, sstride,
-                       out);
+                       out, idx);
     VI_HIP(hipGetLastError());
     return VI_OK;
 }
@@ -712,6 +743,56 @@ extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, doub
 // the system at the first iterate alpha0 is decomposed with eigenvectors, X(alpha0) = V L V^T, and
 // D1 = V^T AWA V, D2 = V^T R V, yt = V^T y are formed; every later iterate then solves the rotated system
 // D1 + alpha D2 (3-10 Jacobi sweeps instead of 17-24 in the rank-deficient regime) and maps back C = V c'.
+namespace {
+// phase 1 of setting up rotated systems: X(alpha0) of bc records formed, scaled and decomposed (cold), the truncated solution
+// to Cc, the rotation logs to `log`, the rounds they hold to nrd
+int prep_decompose(vi_ctx* c, int64_t bc, int N, const double* d_AWA, const int32_t* recc, const double* alpha0c,
+                   const double* d_R, const double* d_y, double rcond, double* Cc, int32_t* rankc, void* log, double* scl,
+                   double* lam, double* T0, int* nrd)
+{
+    const int NN = N * N;
+    hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, alpha0c, d_R, T0);
+    hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, T0, scl);
+    VI_HIP(hipGetLastError());
+    return vi_jacobi_solve(c, bc, N, T0, scl, d_y, recc, rcond, Cc, rankc, log, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd,
+                           JACOBI_FLOOR_COLD);
+}
+
+// phase 2: eigenvectors from the logs, D1 = V^T (AWA V), D2 = V^T (R V) - four batched products in groups of fixed size
+// (see GEMM_GROUP) - and yt = V^T y.  parr: room for 6 pointer arrays of Bcp entries.
+int prep_finish(vi_ctx* c, int64_t bc, int N, const void* log, const int* nrd, const double* d_AWA, const int32_t* recc,
+                const double* d_R, const double* d_y, double* Vc, double* D1c, double* D2c, double* ytc, double* T0, double* T1,
+                double* scrT, double* scrD, const double** parr, int64_t Bcp)
+{
+    const int NN = N * N;
+    const double** pT0 = parr;
+    const double** pV = pT0 + Bcp;
+    const double** pT1 = pV + Bcp;
+    const double** pR = pT1 + Bcp;
+    const double** pD1 = pR + Bcp;
+    const double** pD2 = pD1 + Bcp;
+    int rc = vi_jacobi_vectors(c, bc, N, log, JACOBI_MAX_SWEEPS, nrd, Vc);
+    if (rc != VI_OK) return rc;
+    hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, T0);
+    VI_HIP(hipGetLastError());
+    if ((rc = group_ptrs(c, bc, T0, NN, nullptr, 0, pT0)) != VI_OK) return rc;
+    if ((rc = group_ptrs(c, bc, Vc, NN, nullptr, 0, pV)) != VI_OK) return rc;
+    if ((rc = group_ptrs(c, bc, T1, NN, scrT, NN, pT1)) != VI_OK) return rc;
+    if ((rc = group_ptrs(c, bc, d_R, 0, nullptr, 0, pR)) != VI_OK) return rc;
+    if ((rc = group_ptrs(c, bc, D1c, NN, scrD, NN, pD1)) != VI_OK) return rc;
+    if ((rc = group_ptrs(c, bc, D2c, NN, scrD, NN, pD2)) != VI_OK) return rc;
+    if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pT0, N, pV, N, pT1, N, bc)) != VI_OK) return rc;
+    if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD1, N, bc)) != VI_OK)
+        return rc;
+    if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pR, N, pV, N, pT1, N, bc)) != VI_OK) return rc;
+    if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD2, N, bc)) != VI_OK)
+        return rc;
+    hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vc, nullptr, d_y, recc, ytc);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+}  // namespace
+
 extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                                    const double* d_alpha0, const double* d_R, const double* d_y, double rcond,
                                    double* d_C, int32_t* d_rank, double* d_V, double* d_D1, double* d_D2, double* d_yt)
@@ -744,46 +825,71 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     double* T1 = T0 + (size_t)Bc * NN;
     double* scrT = T1 + (size_t)Bc * NN;   // results of the padding entries of the last product group
     double* scrD = scrT + (size_t)GEMM_GROUP * NN;
-    const double** pT0 = (const double**)(scrD + (size_t)GEMM_GROUP * NN);
-    const double** pV = pT0 + Bcp;
-    const double** pT1 = pV + Bcp;
-    const double** pR = pT1 + Bcp;
-    const double** pD1 = pR + Bcp;
-    const double** pD2 = pD1 + Bcp;
-    int* nrd = (int*)(pD2 + Bcp);
+    const double** parr = (const double**)(scrD + (size_t)GEMM_GROUP * NN);
+    int* nrd = (int*)(parr + 6 * Bcp);
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
-        const int32_t* recc = d_rec + i0;
-        double* Vc = d_V + i0 * NN;
-        hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, d_alpha0 + i0, d_R, T0);
-        hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, T0, scl);
-        VI_HIP(hipGetLastError());
-        rc = vi_jacobi_solve(c, bc, N, T0, scl, d_y, recc, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
-                             JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd, JACOBI_FLOOR_COLD);
+        rc = prep_decompose(c, bc, N, d_AWA, d_rec + i0, d_alpha0 + i0, d_R, d_y, rcond, d_C + i0 * N,
+                            d_rank ? d_rank + i0 : nullptr, ws, scl, lam, T0, nrd);
         if (rc != VI_OK) return rc;
-        rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, Vc);
+        rc = prep_finish(c, bc, N, ws, nrd, d_AWA, d_rec + i0, d_R, d_y, d_V + i0 * NN, d_D1 + i0 * NN, d_D2 + i0 * NN,
+                         d_yt + i0 * N, T0, T1, scrT, scrD, parr, Bcp);
         if (rc != VI_OK) return rc;
-        // D1 = V^T (AWA V), D2 = V^T (R V): four batched products in groups of fixed size (see GEMM_GROUP)
-        hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, T0);
-        VI_HIP(hipGetLastError());
-        if ((rc = group_ptrs(c, bc, T0, NN, nullptr, 0, pT0)) != VI_OK) return rc;
-        if ((rc = group_ptrs(c, bc, Vc, NN, nullptr, 0, pV)) != VI_OK) return rc;
-        if ((rc = group_ptrs(c, bc, T1, NN, scrT, NN, pT1)) != VI_OK) return rc;
-        if ((rc = group_ptrs(c, bc, d_R, 0, nullptr, 0, pR)) != VI_OK) return rc;
-        if ((rc = group_ptrs(c, bc, d_D1 + i0 * NN, NN, scrD, NN, pD1)) != VI_OK) return rc;
-        if ((rc = group_ptrs(c, bc, d_D2 + i0 * NN, NN, scrD, NN, pD2)) != VI_OK) return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pT0, N, pV, N, pT1, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD1, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pR, N, pV, N, pT1, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pV, N, pT1, N, pD2, N, bc)) != VI_OK)
-            return rc;
-        hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vc, nullptr, d_y, recc, d_yt + i0 * N);
-        VI_HIP(hipGetLastError());
     }
     return VI_OK;
+}
+
+// The two phases of vi_warm_prepare_f64 as separate calls, with the rotation logs in a buffer of the caller
+// (vi_rotation_log_bytes(N) per system): a record fitted alone decomposes the systems at the middle of ALL its candidate
+// brackets in the launch of its bracket walk (room for 256 systems, as long as the slowest one) and finishes - eigenvectors
+// and the three products - only the one the walk then points at.
+extern "C" size_t vi_rotation_log_bytes(int32_t N) { return vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS); }
+
+extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
+                                const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,
+                                int32_t* d_rank, void* d_log, int32_t* d_nround)
+{
+    VI_REQUIRE(c && d_AWA && d_rec && d_alpha0 && d_R && d_y && d_C && d_log && d_nround, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    if (!vi_jacobi_vectors_supported(N)) {
+        vi_set_error("vi_decompose_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)B * ((size_t)(N + 1 + NN) * sizeof(double)) + 1024, &ws);
+    if (rc != VI_OK) return rc;
+    double* scl = (double*)ws;
+    double* lam = scl + B;
+    double* T0 = lam + (size_t)B * N;
+    return prep_decompose(c, B, N, d_AWA, d_rec, d_alpha0, d_R, d_y, rcond, d_C, d_rank, d_log, scl, lam, T0, d_nround);
+}
+
+extern "C" int vi_warm_finish_f64(vi_ctx* c, int64_t B, int32_t N, const void* d_log, const int32_t* d_nround,
+                                  const double* d_AWA, const int32_t* d_rec, const double* d_R, const double* d_y,
+                                  double* d_V, double* d_D1, double* d_D2, double* d_yt)
+{
+    VI_REQUIRE(c && d_log && d_nround && d_AWA && d_rec && d_R && d_y && d_V && d_D1 && d_D2 && d_yt, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    if (!vi_jacobi_vectors_supported(N)) {
+        vi_set_error("vi_warm_finish_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    const int64_t Bp = group_pad(B);
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)(2 * B + 2 * GEMM_GROUP) * NN * sizeof(double) + (size_t)6 * Bp * sizeof(void*) + 1024, &ws);
+    if (rc != VI_OK) return rc;
+    double* T0 = (double*)ws;
+    double* T1 = T0 + (size_t)B * NN;
+    double* scrT = T1 + (size_t)B * NN;
+    double* scrD = scrT + (size_t)GEMM_GROUP * NN;
+    const double** parr = (const double**)(scrD + (size_t)GEMM_GROUP * NN);
+    return prep_finish(c, B, N, d_log, d_nround, d_AWA, d_rec, d_R, d_y, d_V, d_D1, d_D2, d_yt, T0, T1, scrT, scrD, parr, Bp);
 }
 
 extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_D1, const double* d_D2,
@@ -949,6 +1055,98 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_basis + i0, cp, d_C + i0 * N);
+        VI_HIP(hipGetLastError());
+    }
+    return VI_OK;
+}
+
+// Re-basing of rotated systems.  Brent's iterates close in on the root within a few steps, and the cost of a warm solve
+// grows with the distance between alpha and the alpha0 the rotated system was set up at (measured, N = 144: 13 sweeps at
+// 0.5 decades, 5-9 at 0.1, 3 at 1e-3, 2 at 1e-6, 1 at 1e-9; tools/exp_rebase_sweeps.py) - the middle of the unit bracket,
+// typically 0.1-0.5 decades from the root.  For B (slot, record, alpha) triples this call solves (D1 + alpha D2) c' = yt
+// like vi_warm_solve_f64 (C = V c' is returned) AND moves the slot's basis to alpha: the eigenvectors Vw of the rotated
+// system come out of the rotation log, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V, yt = V^T y are formed again from the
+// untransformed matrices (no compounding of the transform's rounding).  One warm solve + the eigenvector replay + six
+// small products instead of a cold decomposition.
+extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const double* d_R, const double* d_y,
+                                  const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
+                                  double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank)
+{
+    VI_REQUIRE(c && d_AWA && d_R && d_y && d_rec && d_slot && d_alpha && d_V && d_D1 && d_D2 && d_yt && d_C, "null argument");
+    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    if (B == 0) return VI_OK;
+    if (!vi_jacobi_vectors_supported(N) || N * N > 24 * 1024) {
+        vi_set_error("vi_warm_rebase_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_HIP(hipSetDevice(c->device));
+    const int NN = N * N;
+    const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+    const size_t per = logb + sizeof(double) + sizeof(int) + (size_t)3 * NN * sizeof(double) + (size_t)N * sizeof(double) +
+                       8 * sizeof(void*);
+    int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
+    if (Bc < 1) Bc = 1;
+    if (Bc > B) Bc = B;
+    const int64_t Bcp = group_pad(Bc);
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)Bc * per + (size_t)2 * GEMM_GROUP * NN * sizeof(double) + 8 * GEMM_GROUP * sizeof(void*) + 1024,
+                              &ws);
+    if (rc != VI_OK) return rc;
+    char* wp = (char*)ws + (size_t)Bc * logb;
+    double* scl = (double*)wp;
+    double* X = scl + Bc;                       // the scaled rotated system, later AWA[rec]
+    double* Vw = X + (size_t)Bc * NN;           // eigenvectors of the rotated system, later a product
+    double* Vn = Vw + (size_t)Bc * NN;          // V Vw
+    double* cp = Vn + (size_t)Bc * NN;
+    double* scrA = cp + (size_t)Bc * N;
+    double* scrB = scrA + (size_t)GEMM_GROUP * NN;
+    const double** pX = (const double**)(scrB + (size_t)GEMM_GROUP * NN);
+    const double** pVold = pX + Bcp;
+    const double** pVw = pVold + Bcp;
+    const double** pVn = pVw + Bcp;
+    const double** pR = pVn + Bcp;
+    const double** pD1 = pR + Bcp;
+    const double** pD2 = pD1 + Bcp;
+    const double** pVslot = pD2 + Bcp;
+    int* nrd = (int*)(pVslot + Bcp);
+    for (int64_t i0 = 0; i0 < B; i0 += Bc) {
+        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+        const int32_t* slotc = d_slot + i0;
+        const int32_t* recc = d_rec + i0;
+        hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, d_D1, d_D2, slotc,
+                           slotc, d_alpha + i0, X, scl);
+        VI_HIP(hipGetLastError());
+        rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, slotc, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS,
+                             nullptr, nullptr, 0, nrd, JACOBI_FLOOR_WARM);
+        if (rc != VI_OK) return rc;
+        hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V, slotc, cp,
+                           d_C + i0 * N);
+        VI_HIP(hipGetLastError());
+        rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, Vw);
+        if (rc != VI_OK) return rc;
+        // V_new = V_old Vw (into Vn, then back into the slots), then the rotated system from the untransformed matrices
+        if ((rc = group_ptrs(c, bc, d_V, NN, nullptr, 0, pVold, slotc)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, Vw, NN, scrA, NN, pVw)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, Vn, NN, scrB, NN, pVn)) != VI_OK) return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pVold, N, pVw, N, pVn, N, bc)) != VI_OK)
+            return rc;
+        hipLaunchKernelGGL(k_scatter_mat, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, Vn, slotc, d_V);
+        hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, X);
+        VI_HIP(hipGetLastError());
+        if ((rc = group_ptrs(c, bc, X, NN, nullptr, 0, pX)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_R, 0, nullptr, 0, pR)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_D1, NN, scrB, NN, pD1, slotc)) != VI_OK) return rc;
+        if ((rc = group_ptrs(c, bc, d_D2, NN, scrB, NN, pD2, slotc)) != VI_OK) return rc;
+        // (pVn reads Vn, which still holds V_new; pVw now names the product buffer)
+        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pX, N, pVn, N, pVw, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pVn, N, pVw, N, pD1, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pR, N, pVn, N, pVw, N, bc)) != VI_OK)
+            return rc;
+        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pVn, N, pVw, N, pD2, N, bc)) != VI_OK)
+            return rc;
+        hipLaunchKernelGGL(k_vt_vec_slot, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vn, d_y, recc, slotc, d_yt);
         VI_HIP(hipGetLastError());
     }
     return VI_OK;

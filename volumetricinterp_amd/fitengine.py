@@ -40,13 +40,20 @@ _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.V
 _lib._sig('vi_basis_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_reg_floor_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_rotation_log_bytes', C.c_size_t, C.c_int32)
+_lib._sig('vi_decompose_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_warm_finish_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_warm_rebase_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_chi2_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.c_int32, C.c_double, C.c_double, _lib.VOIDP, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.POINTER(C.c_double))
 _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, C.c_double, _lib.VOIDP)
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -86,6 +93,8 @@ class FitEngine(object):
         self._bounds = [0, 0]
         self._same_below = {}
         self._walk_cache = {}
+        self._warm_slot = {}
+        self._spec_slot = {}
         self.stats = dict(solves=0, launches=0)
 
     @classmethod
@@ -260,7 +269,22 @@ class FitEngine(object):
 
     def _warm_reset(self):
         self._warm_slot = {}          # record -> slot of its Brent basis
+        self._spec_slot = {}          # (record, bracket midpoint) -> slot of a basis decomposed alongside the walk
+        self._last_x = {}             # record -> log10(alpha) of its previous root-finder request
+        self._rebased = set()         # records whose rotated system has been moved next to the root
         self._basis_slot = {}         # decade -> slot of the reference system's eigenbasis (shared walk)
+
+    REBASE_WITHIN = 3e-2          # decades between two consecutive root-finder requests of a record
+
+    def _wants_rebase(self, r, x):
+        """Brent's iterates have started to cluster (this request lies within REBASE_WITHIN decades of the record's previous
+        one) and the record's rotated system still sits at the middle of the bracket: move it here, once
+        (vi_warm_rebase_f64).  The rule looks at the record's own requests only, so what a record sees does not depend on
+        the batch it is in."""
+        if r in self._rebased or os.environ.get('VINTERP_REBASE', '1') == '0':
+            return False
+        last = self._last_x.get(r)
+        return last is not None and abs(x - last) < self.REBASE_WITHIN
 
     def _warm_buffers(self, tag):
         T, N = self.T, self.N
@@ -355,7 +379,9 @@ class FitEngine(object):
         forced = (np.array([int(r) in force for r in rec.tolist()], dtype=bool) if force else np.zeros(B, dtype=bool))
         if exact is not None:
             forced = forced | np.asarray(exact, dtype=bool)      # reference-grade requests of the search: cold solves
-        if B == 1 and not is_int[0] and not forced[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot:
+        if (B == 1 and not is_int[0] and not forced[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot
+                and not self._wants_rebase(int(rec[0]), float(log10a[0]))):
+            self._last_x[int(rec[0])] = float(log10a[0])
             # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
             scratch = self._buf('w_one', (N + 8,))
@@ -376,18 +402,29 @@ class FitEngine(object):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
+        if (self.T == 1 and B >= 8 and is_int.all() and not forced.any() and not self._warm_slot and not self._spec_slot
+                and os.environ.get('VINTERP_SPECULATE', '1') != '0'):
+            return self._walk_with_speculative_bases(rec, log10a, alpha, name, trace)
         shared = (is_int & ~forced if (self._ref_rec is not None and self.shared_walk_enabled())
                   else np.zeros(B, dtype=bool))
         # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
         # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
         warm = np.zeros(B, dtype=bool)
         prep = np.zeros(B, dtype=bool)
+        rebase = np.zeros(B, dtype=bool)
         by_rec = {}
         for j in np.nonzero(~is_int & ~forced)[0].tolist():
             by_rec.setdefault(int(rec[j]), []).append(j)
         need = {}
         for r, js in by_rec.items():
             warm[js] = True
+            if len(js) == 1:
+                x = float(log10a[js[0]])
+                if r in self._warm_slot and self._wants_rebase(r, x):
+                    warm[js] = False
+                    rebase[js] = True
+                    self._rebased.add(r)
+                self._last_x[r] = x
             if r not in self._warm_slot:
                 # The rotated system of a record is set up at the MIDDLE of its unit bracket, 10^(floor(x) + 1/2),
                 # whatever the request that triggers it (Brent's first iterate, a multisection sample): the warm chi^2 is
@@ -397,6 +434,9 @@ class FitEngine(object):
                 # is a multisection sample, then got another basis, other rounding and sometimes another of the several
                 # roots of a default-order bracket than the same record inside a batch.)
                 need[r] = math.floor(float(log10a[js[0]])) + 0.5
+                if (r, need[r]) in self._spec_slot:      # decomposed alongside the walk (_walk_with_speculative_bases)
+                    self._finish_speculative(r, self._spec_slot[(r, need[r])])
+                    del need[r]
         if need:
             recs_n = sorted(need)
             scratchC = self._buf('wp_scratchC', (len(recs_n), N))
@@ -406,8 +446,9 @@ class FitEngine(object):
         cold = (is_int & ~shared) | forced               # forced: records whose search is being redone cold
         sh_idx = np.nonzero(shared)[0]
         sh_idx = sh_idx[np.argsort(log10a[sh_idx], kind='stable')]          # by decade: one basis after the other
-        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], np.nonzero(warm)[0]])
-        nc, nsh, npre, nw = int(cold.sum()), len(sh_idx), int(prep.sum()), int(warm.sum())
+        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], np.nonzero(warm)[0],
+                                np.nonzero(rebase)[0]])
+        nc, nsh, npre, nw, nrb = int(cold.sum()), len(sh_idx), int(prep.sum()), int(warm.sum()), int(rebase.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
@@ -460,6 +501,15 @@ class FitEngine(object):
         if nw:
             self._warm_solve('w_', self._warm_slot, rec_o[o:o + nw], dal.offset_ptr(o), nw, dCall.offset_ptr(o * N),
                              drank.offset_ptr(o))
+            o += nw
+        if nrb:
+            dV, dD1, dD2, dyt = self._warm_buffers('w_')
+            sl = np.array([self._warm_slot[int(r)] for r in rec_o[o:o + nrb]], dtype=np.int32)
+            dslot = self._buf('w_rbslot', (nrb,), np.int32).upload(sl)
+            _lib.check(_lib.lib.vi_warm_rebase_f64(h, nrb, N, self.dAWA.ptr, self.R[name].ptr, self.dy.ptr, drec.offset_ptr(o),
+                                                   dslot.ptr, dal.offset_ptr(o), EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr,
+                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_warm_rebase_f64')
+            self.stats['rebased'] = self.stats.get('rebased', 0) + nrb
         dchi = self._buf('w_chi2', (B,))
         _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dCall.ptr, drec.ptr, self.dW.ptr, self.db.ptr,
                                         dchi.ptr), 'vi_chi2_f64')
@@ -468,13 +518,71 @@ class FitEngine(object):
         out = np.empty(B)
         out[order] = tmp
         if trace:
-            print('[search round] B=%d cold=%d shared=%d prepare=%d warm=%d  %.2f ms  log10a[0]=%.12f' %
-                  (B, nc, nsh, npre, nw, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            print('[search round] B=%d cold=%d shared=%d prepare=%d warm=%d rebase=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, nsh, npre, nw, nrb, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
-        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw
+        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nrb
         self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
+
+    def _walk_with_speculative_bases(self, rec, log10a, alpha, name, trace):
+        """The bracket walk of a record fitted ALONE, with the rotated systems of all its candidate brackets.
+
+        A single record's fit is a chain of dependent launches on an otherwise empty GPU, and a launch of up to 256 systems
+        lasts as long as its slowest one.  The walk (one launch: every decade at once) is followed by the decomposition, with
+        eigenvectors, of X at the middle of the bracket it finds - another cold solve, another 3.5 ms of the ~28.  Which
+        bracket that will be is not known before the walk is done, but there are at most 101 candidates and the launch
+        has room: the walk systems and the midpoint systems of all brackets above the record's floor are decomposed in
+        ONE launch, and the basis Brent needs is there when the walk ends.  Same kernels on the same systems: the walk
+        values and the chosen basis are bit for bit what the two separate launches gave."""
+        N, h, B = self.N, self.ctx.handle, len(rec)
+        kfl = self._same_below.get(name)
+        mids = []
+        for r, k in sorted(set(zip(rec.tolist(), log10a.tolist()))):
+            lo = k - 1.
+            if lo >= -101. and (kfl is None or lo >= kfl[r]):
+                mids.append((int(r), k - 0.5))
+        n = B + len(mids)
+        recs = np.concatenate([rec, np.array([r for r, _ in mids], dtype=np.int32)]).astype(np.int32)
+        als = np.concatenate([alpha, np.power(10., np.array([x for _, x in mids], dtype=np.float64))])
+        logb = int(_lib.lib.vi_rotation_log_bytes(N))
+        dlog = self._buf('sp_log', (n * (logb // 8),))
+        dnr = self._buf('sp_nround', (n,), np.int32)
+        dr = self._buf('sp_rec', (n,), np.int32).upload(recs)
+        da = self._buf('sp_alpha', (n,)).upload(als)
+        dC = self._buf('sp_C', (n, N))
+        drk = self._buf('sp_rank', (n,), np.int32)
+        _lib.check(_lib.lib.vi_decompose_f64(h, n, N, self.dAWA.ptr, dr.ptr, da.ptr, self.R[name].ptr, self.dy.ptr, EPS,
+                                             dC.ptr, drk.ptr, dlog.ptr, dnr.ptr), 'vi_decompose_f64')
+        for j, key in enumerate(mids):
+            self._spec_slot[key] = B + j          # index of the system's rotation log
+        self._spec_name = name
+        dchi = self._buf('sp_chi2', (B,))
+        _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dC.ptr, dr.ptr, self.dW.ptr, self.db.ptr, dchi.ptr),
+                   'vi_chi2_f64')
+        out = np.empty(B)
+        _lib.check(_lib.lib.vi_d2h(h, out.ctypes.data_as(_lib.VOIDP), dchi.ptr, out.nbytes), 'd2h')
+        self.stats['solves'] += n
+        self.stats['launches'] += 1
+        self.stats['speculative_bases'] = self.stats.get('speculative_bases', 0) + len(mids)
+        if trace:
+            print('[search round] B=%d walk + %d speculative bracket bases in one launch' % (B, len(mids)))
+        return out
+
+    def _finish_speculative(self, r, j):
+        """Eigenvectors and rotated system of record r from rotation log j of the walk launch -> the record's slot."""
+        N, h = self.N, self.ctx.handle
+        logb = int(_lib.lib.vi_rotation_log_bytes(N))
+        slot = len(self._warm_slot)
+        self._warm_slot[r] = slot
+        dV, dD1, dD2, dyt = self._warm_buffers('w_')
+        dlog, dnr = self._bufs['sp_log'], self._bufs['sp_nround']
+        dr = self._buf('sp_rec1', (1,), np.int32).upload(np.array([r], dtype=np.int32))
+        _lib.check(_lib.lib.vi_warm_finish_f64(h, 1, N, dlog.offset_ptr(j * (logb // 8)), dnr.offset_ptr(j), self.dAWA.ptr,
+                                               dr.ptr, self.R[self._spec_name].ptr, self.dy.ptr, dV.offset_ptr(slot * N * N),
+                                               dD1.offset_ptr(slot * N * N), dD2.offset_ptr(slot * N * N),
+                                               dyt.offset_ptr(slot * N)), 'vi_warm_finish_f64')
 
     def default_prefetch(self):
         # walk prefetch: the whole alpha = 0 .. -101 table in one launch for a single record (latency-bound), a few steps
@@ -500,7 +608,10 @@ class FitEngine(object):
         # 117, T = 16  153 vs 145 - the refused round also sets up the rotated system Brent then uses).
         # Only where the in-LDS solver serves the rounds: at orders beyond it (N > 180, rocSOLVER, ~0.15 s per solve
         # at N = 1152) K extra solves per round are far dearer than Brent's dependent ones.
-        if mode == 'multisection' or (self.T <= 4 and self.warm_enabled()):
+        # Not at the default order and beyond (N >= 100): there the guard refuses on most brackets and the attempt is pure
+        # cost - one launch of 254 warm systems, 3.1 ms of a 28.6 ms single-record fit (bench.py, 25.5 ms without it; the
+        # rotated system sits at the middle of the bracket either way now, so Brent's steps and the answer are the same).
+        if mode == 'multisection' or (self.T <= 4 and self.warm_enabled() and self.N < 100):
             return int(max(15, min(255, 256 // max(1, self.T) - 1)))
         return 0
 
@@ -540,9 +651,6 @@ class FitEngine(object):
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
-            # (skipping the multisection round once it has been refused on this geometry was measured and lost: the round's
-            # middle sample is where the rotated system gets set up, and with the basis at Brent's first iterate instead
-            # the warm chi^2 values are noisier - 29 Brent iterations instead of 14, 53 ms per record instead of 31)
         self._force_cold = set()
         return params, infos
 
