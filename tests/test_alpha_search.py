@@ -296,3 +296,76 @@ def test_walk_over_a_known_table_equals_the_step_by_step_walk(refine):
             assert got[0] == want[0], (case, want, got)
             if want[0] == 'too_smooth':
                 assert got[2]['sf'] == want[1]
+
+
+def test_refined_search_sees_the_reference_grade_values_only_where_it_matters():
+    """With `refine` the walk may come from an approximate evaluator: its values only decide signs (unless within the margin of
+    nu), the bracket ends are asked for again as Exact, and Brent runs on the exact function - so a noisy walk gives the
+    root of the noise-free search, bit for bit, at the price of two extra evaluations per record."""
+    def chi2_true(x):
+        return 450. + 300. / (1. + math.exp(-(x + 28.3) * 2.))          # rises through nu = 0.6 * 1000 near -28.3
+
+    calls = dict(plain=0, exact=0)
+
+    def noisy(rec, la, exact=None):
+        out = []
+        for j, a in enumerate(la):
+            e = exact is not None and exact[j]
+            calls['exact' if e else 'plain'] += 1
+            noise = 0. if (e or a != math.floor(a)) else 2e-5 * math.sin(a * 7.3)
+            out.append(chi2_true(a) * (1. + noise))
+        return np.array(out)
+    clean = AS.run_batched([1000, 1000], lambda r, a: np.array([chi2_true(x) for x in a]), prefetch=8)
+    got = AS.run_batched([1000, 1000], noisy, prefetch=8, refine=True)
+    assert got[0] == clean[0] and got[1] == clean[1] == ['root', 'root']
+    assert calls['exact'] == 4                                           # the two ends of each record's bracket
+    # a walk value inside the sign margin of nu is asked for again as well
+    calls.update(plain=0, exact=0)
+    near = lambda x: 600. * (1. + 2e-4) if x == -10. else chi2_true(x)
+    AS.run_batched([1000], lambda r, a, exact=None: (calls.__setitem__('exact', calls['exact'] + int(np.sum(exact)))
+                                                    if exact is not None else None) or np.array([near(x) for x in a]),
+                   prefetch=8, refine=True)
+    assert calls['exact'] == 3
+
+
+def test_refined_search_redoes_the_walk_when_the_ends_contradict_it():
+    """If the exact values at the bracket ends do not change sign (the approximate walk was wrong about one of them), the
+    record's walk is redone on exact values - the whole table in one request - and the answer is that of the exact function."""
+    def exact_f(x):
+        return 450. + 300. / (1. + math.exp(-(x + 28.3) * 2.))
+
+    def approx_f(x):                      # wrong by 30 % at one decade: a spurious sign change between -11 and -12
+        return exact_f(x) * (0.7 if x == -12. else 1.)
+    seen = []
+
+    def ev(rec, la, exact=None):
+        ex = np.zeros(len(la), bool) if exact is None else exact
+        seen.append((len(la), int(np.sum(ex))))
+        return np.array([exact_f(x) if e or x != math.floor(x) else approx_f(x) for x, e in zip(la, ex)])
+    got = AS.run_batched([1000], ev, prefetch=8, refine=True)
+    clean = AS.run_batched([1000], lambda r, a: np.array([exact_f(x) for x in a]), prefetch=8)
+    assert got[0] == clean[0] and got[2][0]['walk_redone_exact']
+    assert (102, 102) in seen                                            # the whole table, exact, in one request
+
+
+def test_polish_driver_stops_at_ftol_or_at_a_jump():
+    """run_polish_batched: smooth functions end when |f| <= ftol (a few Brent steps), a sign-changing jump ends when it is
+    confined to xtol - in about ten rounds, not the ~40 of bisecting to brentq's 2e-12 - and what a record gets does not
+    depend on which other records are polished with it."""
+    fs = {0: lambda x: (x + 27.3) * 50., 1: lambda x: (-5. if x < -27.123456 else 7.),
+          2: lambda x: math.tan((x + 27.5) * 1.2) * 3., 3: lambda x: (x + 27.45)**3 * 1e4 + (x + 27.45)}
+    rounds = [0]
+
+    def fb(rec, xs):
+        rounds[0] += 1
+        return np.array([fs[int(r)](float(x)) for r, x in zip(rec, xs)])
+    br = {i: (-27.6, -27.0, fs[i](-27.6), fs[i](-27.0)) for i in fs}
+    out = AS.run_polish_batched(br, fb, {i: 1e-3 for i in fs})
+    assert rounds[0] <= 12
+    assert out[0][3] == 'ftol' and abs(out[0][0] + 27.3) < 1e-4
+    assert out[2][3] == 'ftol' and abs(fs[2](out[2][0])) <= 1e-3
+    assert out[3][3] == 'ftol' and abs(fs[3](out[3][0])) <= 1e-3
+    assert out[1][3] == 'jump' and abs(out[1][0] + 27.123456) <= 1e-7 and abs(out[1][2] - out[1][0]) <= 1e-7
+    for i in fs:                                                        # alone: the same answer
+        alone = AS.run_polish_batched({i: br[i]}, fb, {i: 1e-3})
+        assert alone[i] == out[i], i

@@ -22,7 +22,8 @@ for j, x0 in ((0, -26.37), (1, -25.4), (3, -26.6)):
     rec = ctx.to_device(np.zeros(1, np.int32))
     dV = ctx.empty((1, N, N)); dD1 = ctx.empty((1, N, N)); dD2 = ctx.empty((1, N, N)); dyt = ctx.empty((1, N)); dC0 = ctx.empty((1, N))
     drk = ctx.empty((1,), np.int32); dC = ctx.empty((1, N))
-    _lib.check(_lib.lib.vi_warm_prepare_f64(h, 1, N, dAWA.ptr, rec.ptr, ctx.to_device(np.array([10.0**x0])).ptr, dR.ptr, dy.ptr, EPS,
+    da0 = ctx.to_device(np.array([10.0**x0]))
+    _lib.check(_lib.lib.vi_warm_prepare_f64(h, 1, N, dAWA.ptr, rec.ptr, da0.ptr, dR.ptr, dy.ptr, EPS,
                                             dC0.ptr, drk.ptr, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr), 'prep')
     row = []
     for dx in (0.5, 0.2, 0.1, 3e-2, 1e-2, 1e-3, 1e-4, 1e-6, 1e-9, 0.):

@@ -41,7 +41,8 @@ print('%4s | %s' % ('k', ' | '.join('rec %d: cold  shared  dchi2/chi2 ' % j for 
 tot_c = tot_s = 0
 for k in list(range(0, -50, -2)) + [-60, -80, -100]:
     al = ctx.to_device(np.array([10.0**k]))
-    _lib.check(_lib.lib.vi_warm_prepare_f64(h, 1, N, dAWA.ptr, ctx.to_device(np.array([T], np.int32)).ptr, al.ptr, dR.ptr, dy.ptr,
+    dref = ctx.to_device(np.array([T], np.int32))
+    _lib.check(_lib.lib.vi_warm_prepare_f64(h, 1, N, dAWA.ptr, dref.ptr, al.ptr, dR.ptr, dy.ptr,
                                             EPS, dC0.ptr, drk.ptr, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr), 'prep')
     V = dV.download()[0]
     # which orientation does the library store V in?  D2 = V^T R V must be reproduced

@@ -137,13 +137,16 @@ class Exact(tuple):
 WALK_SIGN_MARGIN = 1e-3
 
 
-def chi2_search_gen(npts, multisection=0, refine=False):
+def chi2_search_gen(npts, multisection=0, refine=False, prefetch=1):
     """Coroutine form of Interpolate.chi2 (interpolate.py:152-218) for one record.
 
     Yields log10(alpha) (or a tuple of them), receives chi^2 at that alpha (or a list).  Returns
     (outcome, alpha, info) with outcome in {'too_smooth', 'no_root', 'root'}; alpha is 0, NaN or 10**root as
     in the reference.  multisection = K > 0: try the guarded K-point multisection first (see multisection_gen),
     falling back to the Brent iteration when the bracket is not provably single-rooted.
+
+    prefetch: a walk value that is not known yet is asked for together with the next prefetch - 1 decades below it (one
+    tuple request; the extra evaluations are harmless, the reference would have reached most of them anyway).
 
     refine: the evaluator serves the bracket walk from a cheaper path whose chi^2 carries noise (the shared bases of
     FitEngine, ~1e-5 relative next to the poles of chi^2) and can serve ``Exact`` requests from its reference-grade one.
@@ -166,6 +169,16 @@ def chi2_search_gen(npts, multisection=0, refine=False):
         for a, c in zip(table, (yield Exact(table))):
             memo_x[a] = c
     walk = memo_x if all_exact else memo
+
+    def fetch(a):                      # a walk value that is not known yet, with the decades below it
+        if prefetch <= 1:
+            walk[a] = yield a
+            return walk[a]
+        ks = tuple(a - j for j in range(int(prefetch)) if a - j >= -101. and (a - j) not in walk)
+        for k, v in zip(ks, (yield ks)):
+            walk[k] = v
+        return walk[a]
+
     bracket = False
     alpha = alpha0 = 0.
     val = val0 = 1.
@@ -199,7 +212,7 @@ def chi2_search_gen(npts, multisection=0, refine=False):
         # (the two look-ups of the walk are written out: a sub-generator per step cost more than the step)
         c = walk.get(alpha)
         if c is None:
-            c = walk[alpha] = yield alpha
+            c = yield from fetch(alpha)
         if margin >= 0. and not abs(c - nu) > margin * nu:           # too close to nu for a sign from an approximate value
             c = memo_x.get(alpha)
             if c is None:
@@ -214,7 +227,7 @@ def chi2_search_gen(npts, multisection=0, refine=False):
             alpha = alpha - 1.
             c = walk.get(alpha)
             if c is None:
-                c = walk[alpha] = yield alpha
+                c = yield from fetch(alpha)
             if margin >= 0. and not abs(c - nu) > margin * nu:
                 c = memo_x.get(alpha)
                 if c is None:
@@ -286,7 +299,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False)
         if n is None:
             results[i] = ('skipped', float('nan'), {})
             continue
-        g = chi2_search_gen(n, multisection=multisection, refine=refine)
+        g = chi2_search_gen(n, multisection=multisection, refine=refine, prefetch=prefetch)
         gens[i] = g
         pending[i] = next(g)
 
@@ -329,14 +342,6 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False)
             exact.append(False)
             rec.append(i)
             alp.append(a)
-            # walk prefetch: integer alphas continue downwards; harmless extra evaluations
-            if prefetch and a == math.floor(a) and -100. <= a <= 0.:
-                for k in range(1, prefetch):
-                    ak = a - k
-                    if ak >= -101. and ak not in cache[i]:
-                        rec.append(i)
-                        alp.append(ak)
-                        exact.append(False)
         if any(exact):
             vals = chi2_batch(np.asarray(rec, dtype=np.int32), np.asarray(alp, dtype=np.float64),
                               np.asarray(exact, dtype=bool))

@@ -156,7 +156,7 @@ class FitEngine(object):
         self._ref_host = [(Wref, bref)]
         self._set_reference(Wref, bref)
 
-    PIPELINE_MIN_RECORDS = 256
+    PIPELINE_MIN_RECORDS = 320
 
     def pipelines(self):
         """Number of concurrent fit pipelines a batch is split into (fit_resident)."""
@@ -948,6 +948,20 @@ class FitEngine(object):
             Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov)
             return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
         return self.fit_resident(npts, calccov=calccov, prefetch=prefetch, multisection=multisection)
+
+    def solve_timing(self, enable=-1):
+        """Context.solve_timing over every context this engine drives (its own and those of its pipelines): sums, except
+        max_ms.  With several pipelines the launches overlap in time, so total_ms exceeds the wall time they took."""
+        ctxs = [self.ctx] + [sub.ctx for sub in (self._subs or [])[1:]]
+        tot = None
+        for cx in ctxs:
+            st = cx.solve_timing(enable)
+            if tot is None:
+                tot = dict(st)
+            else:
+                for k, v in st.items():
+                    tot[k] = max(tot[k], v) if k == 'max_ms' else tot[k] + v
+        return tot
 
     def _close_subs(self):
         for k, sub in enumerate(self._subs or []):
