@@ -345,7 +345,7 @@ def test_refined_search_redoes_the_walk_when_the_ends_contradict_it():
     got = AS.run_batched([1000], ev, prefetch=8, refine=True)
     clean = AS.run_batched([1000], lambda r, a: np.array([exact_f(x) for x in a]), prefetch=8)
     assert got[0] == clean[0] and got[2][0]['walk_redone_exact']
-    assert (102, 102) in seen                                            # the whole table, exact, in one request
+    assert (100, 100) in seen                        # the whole table, exact, in one request (the two ends are known)
 
 
 def test_polish_driver_stops_at_ftol_or_at_a_jump():
