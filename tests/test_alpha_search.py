@@ -369,3 +369,59 @@ def test_polish_driver_stops_at_ftol_or_at_a_jump():
     for i in fs:                                                        # alone: the same answer
         alone = AS.run_polish_batched({i: br[i]}, fb, {i: 1e-3})
         assert alone[i] == out[i], i
+
+
+def test_vectorised_brent_takes_the_coroutines_steps():
+    """BrentBatch (Brent's iteration of all records on arrays) against brentq_gen record by record: same iterates, same
+    roots, iteration counts, other ends - on smooth functions, poles, jumps, flat stretches and exact zeros - and
+    run_batched gives the same answers with either."""
+    rng = np.random.default_rng(11)
+    funcs = []
+    for k in range(60):
+        r, s1 = rng.uniform(-27.9, -27.1), rng.uniform(0.5, 50.)
+        kind = k % 6
+        if kind == 0:
+            funcs.append(lambda x, r=r, s1=s1: s1 * (x - r))
+        elif kind == 1:
+            funcs.append(lambda x, r=r, s1=s1: s1 * ((x - r)**3 + 1e-3 * (x - r)))
+        elif kind == 2:
+            funcs.append(lambda x, r=r, s1=s1: -3. if x < r else s1)                         # a jump
+        elif kind == 3:
+            funcs.append(lambda x, r=r, s1=s1: math.tan((x - r) * 1.4))                       # poles outside the bracket
+        elif kind == 4:
+            funcs.append(lambda x, r=r, s1=s1: s1 * (x - r) + 0.3 * math.sin(400. * x))       # several roots
+        else:
+            funcs.append(lambda x, r=r, s1=s1: 0. if abs(x - r) < 1e-3 else s1 * (x - r))     # exact zeros near the root
+    n = len(funcs)
+    ref = []
+    for f in funcs:
+        g = AS.brentq_gen(-28., -27., fa=f(-28.), fb=f(-27.))
+        xs = []
+        try:
+            x = next(g)
+            while True:
+                xs.append(x)
+                x = g.send(f(x))
+        except StopIteration as stop:
+            ref.append((stop.value, xs))
+    bb = AS.BrentBatch(n)
+    seen = [[] for _ in range(n)]
+    for i, f in enumerate(funcs):
+        bb.add(i, -28., -27., f(-28.), f(-27.))
+    while bb.active.any():
+        idx, xs = bb.requests()
+        for i, x in zip(idx.tolist(), xs.tolist()):
+            seen[i].append(x)
+        bb.feed(idx, np.array([funcs[i](x) for i, x in zip(idx.tolist(), xs.tolist())]))
+    for i in range(n):
+        (root, it, nf, oe), xs = ref[i]
+        assert seen[i] == xs, i
+        assert bb.results[i] == (root, it, nf, oe), (i, bb.results[i], ref[i][0])
+    # the driver, both ways, on chi^2-like functions built from them
+    chi = lambda i, a: 600. + funcs[i](a) if -28. <= a <= -27. else (300. if a < -28. else 900.)
+    ev = lambda rec, la, exact=None: np.array([chi(int(i), float(a)) for i, a in zip(rec, la)])
+    a1 = AS.run_batched([1000] * n, ev, prefetch=8, vector_brent=True)
+    a2 = AS.run_batched([1000] * n, ev, prefetch=8, vector_brent=False)
+    assert a1[0] == a2[0] and a1[1] == a2[1] and a1[3] == a2[3]
+    for i1, i2 in zip(a1[2], a2[2]):
+        assert i1 == i2

@@ -95,6 +95,7 @@ class FitEngine(object):
         self._walk_cache = {}
         self._warm_slot = {}
         self._spec_slot = {}
+        self._basis_x = {}
         self.stats = dict(solves=0, launches=0)
 
     @classmethod
@@ -272,6 +273,7 @@ class FitEngine(object):
         self._spec_slot = {}          # (record, bracket midpoint) -> slot of a basis decomposed alongside the walk
         self._last_x = {}             # record -> log10(alpha) of its previous root-finder request
         self._rebased = set()         # records whose rotated system has been moved next to the root
+        self._basis_x = {}            # record -> log10(alpha) its rotated system sits at
         self._basis_slot = {}         # decade -> slot of the reference system's eigenbasis (shared walk)
 
     REBASE_WITHIN = 3e-2          # decades between two consecutive root-finder requests of a record
@@ -424,6 +426,7 @@ class FitEngine(object):
                     warm[js] = False
                     rebase[js] = True
                     self._rebased.add(r)
+                    self._basis_x[r] = x
                 self._last_x[r] = x
             if r not in self._warm_slot:
                 # The rotated system of a record is set up at the MIDDLE of its unit bracket, 10^(floor(x) + 1/2),
@@ -434,6 +437,7 @@ class FitEngine(object):
                 # is a multisection sample, then got another basis, other rounding and sometimes another of the several
                 # roots of a default-order bracket than the same record inside a batch.)
                 need[r] = math.floor(float(log10a[js[0]])) + 0.5
+                self._basis_x[r] = need[r]
                 if (r, need[r]) in self._spec_slot:      # decomposed alongside the walk (_walk_with_speculative_bases)
                     self._finish_speculative(r, self._spec_slot[(r, need[r])])
                     del need[r]
@@ -446,8 +450,13 @@ class FitEngine(object):
         cold = (is_int & ~shared) | forced               # forced: records whose search is being redone cold
         sh_idx = np.nonzero(shared)[0]
         sh_idx = sh_idx[np.argsort(log10a[sh_idx], kind='stable')]          # by decade: one basis after the other
-        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], np.nonzero(warm)[0],
-                                np.nonzero(rebase)[0]])
+        # warm solves cost more the further alpha is from where the record's rotated system sits: longest first, so
+        # that a launch does not end on one straggler started last
+        w_idx = np.nonzero(warm)[0]
+        if len(w_idx) > 256 and os.environ.get('VINTERP_LPT', '1') != '0':
+            dist = np.abs(log10a[w_idx] - np.array([self._basis_x.get(int(r), 0.) for r in rec[w_idx].tolist()]))
+            w_idx = w_idx[np.argsort(-dist, kind='stable')]
+        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], w_idx, np.nonzero(rebase)[0]])
         nc, nsh, npre, nw, nrb = int(cold.sum()), len(sh_idx), int(prep.sum()), int(warm.sum()), int(rebase.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
