@@ -237,6 +237,26 @@ def test_rbf_estimate_vs_oracle():
         assert np.linalg.norm(out[t] - A @ f['Coeffs'][t]) <= 1e-11 * scale
 
 
+def test_rbf_many_timesteps_tiles_agree():
+    """The radial-basis evaluation computes each exponential once per tile of 16, 4 or 1 timesteps: 37 timesteps (two tiles
+    of 16, one of 4, one single) against the oracle's basis, and row by row against the single-timestep launches."""
+    import oracle
+    from volumetricinterp_amd.estimate import Estimate
+    f = load_golden('fit_rbf')
+    rng = np.random.default_rng(10)
+    T, N = 37, f['Coeffs'].shape[1]
+    Cs = rng.standard_normal((T, N))
+    es = Estimate.from_arrays(Cs, None, np.stack([np.arange(T), np.arange(T) + 1.], axis=1), f['hull_vert'], str(f['cfg']))
+    Q = 1000
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(255, 270, Q), rng.uniform(100e3, 600e3, Q)
+    out = es.evaluate_coeffs(Cs, lat, lon, alt, check_hull=False)
+    A = oracle.RadBasFunOracle.from_config(io.StringIO(str(f['cfg']))).basis(lat, lon, alt)
+    for t in range(T):
+        assert rel(out[t], A @ Cs[t]) <= 1e-12, t
+        one = es.evaluate_coeffs(Cs[t:t + 1], lat, lon, alt, check_hull=False)
+        assert rel(out[t], one[0]) <= 1e-14, t
+
+
 @pytest.mark.parametrize('tag', ['default', 'k3l4cap15', 'k2l5cap12p7'])
 def test_grad_basis_vs_reference(tag):
     """Model.grad_basis (sphharmlag.py:148-184, next row N1): (P, 3, N) against the reference's own output."""

@@ -1026,16 +1026,21 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
     }
     EvalTimer timer(m->ctx);
     int64_t t = 0;
+    // the exponential of a (point, centre) pair is the cost (~20 of the ~28 fp64 operations per pair): it is computed once per
+    // tile of timesteps, so the tile is as wide as the registers allow (16 accumulators; a tile of 4 recomputed every
+    // exponential four times for 16 timesteps: 10.7 ms instead of 3.4 at 1000 centres x 128^3 points)
     while (t < T) {
-        const int tc = (int)((T - t) >= 4 ? 4 : (T - t));
-        if (tc == 4)
-            hipLaunchKernelGGL(k_eval_rbf<4>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
-                               d_lon, d_alt, tc, d_C + t * N, d_mask, F, hull_tol, d_out + t * Q);
-        else
-            hipLaunchKernelGGL(k_eval_rbf<1>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat,
-                               d_lon, d_alt, 1, d_C + t * N, d_mask, F, hull_tol, d_out + t * Q);
+        const int64_t left = T - t;
+        const int tc = left >= 16 ? 16 : left >= 4 ? 4 : 1;
+#define VI_RBF(TT)                                                                                                        \
+    hipLaunchKernelGGL(k_eval_rbf<TT>, dim3(nblocks(Q, BLOCK)), dim3(BLOCK), 0, m->ctx->stream, m->rbf, Q, d_lat, d_lon, \
+                       d_alt, TT, d_C + t * N, d_mask, F, hull_tol, d_out + t * Q)
+        if (tc == 16) VI_RBF(16);
+        else if (tc == 4) VI_RBF(4);
+        else VI_RBF(1);
+#undef VI_RBF
         VI_HIP(hipGetLastError());
-        t += (tc == 4) ? 4 : 1;
+        t += tc;
     }
     return VI_OK;
 }
