@@ -42,7 +42,7 @@ def main():
         reg = ['curvature', '0thorder'][int(rng.integers(0, 2))]
         cap = [10., 15., 12.7][int(rng.integers(0, 3))]
         nb, nr = int(rng.integers(2, 12)), int(rng.integers(5, 60))
-        T = int(rng.integers(1, 6))
+        T = int(rng.integers(1, 6)) if case % 3 else int(rng.integers(8, 48))          # batches: shared walk, refine
         p = os.path.join(d, 'c%d.ini' % case)
         open(p, 'w').write(CFG % (reg, maxk, maxl, cap))
         it = Interpolate(p)
