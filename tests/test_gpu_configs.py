@@ -127,6 +127,36 @@ def test_c1_fit_is_independent_of_the_batch_and_consistent(monkeypatch):
     assert nroot >= 30
 
 
+def test_pipelines_change_nothing_but_the_time(monkeypatch):
+    """fit_resident runs a batch as concurrent sub-batches, each on its own context and host thread (FitEngine.
+    _fit_pipelined): 48 records as one, two and three pipelines give the same alpha, chi^2, coefficients, covariances and
+    search bookkeeping."""
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 48
+    value, error = synth.synth_records(A, T, seed0=3000)
+    W = error**-2.
+    res = {}
+    for k in ('1', '2', '3'):
+        monkeypatch.setenv('VINTERP_PIPELINES', k)
+        res[k] = eng.fit(W, value, [P] * T)
+        assert eng.stats.get('pipelines', 1) == int(k) or k == '1'
+    for k in ('2', '3'):
+        a, b = res['1'], res[k]
+        assert np.array_equal(a['Coeffs'], b['Coeffs'], equal_nan=True)
+        assert np.array_equal(a['chi_sq'], b['chi_sq'], equal_nan=True)
+        assert np.array_equal(a['Covariance'], b['Covariance'], equal_nan=True)
+        assert np.array_equal(a['ranks'], b['ranks'])
+        for t in range(T):
+            x, y = a['reg_params'][t]['curvature'], b['reg_params'][t]['curvature']
+            assert x == y or (np.isnan(x) and np.isnan(y)), (k, t)
+        sa, sb = a['search']['curvature'], b['search']['curvature']
+        assert sa['outcomes'] == sb['outcomes']
+        assert sorted(sa.get('polished_cold', [])) == sorted(sb.get('polished_cold', []))
+        assert [i.get('iterations') for i in sa['info']] == [i.get('iterations') for i in sb['info']]
+    eng.close()
+
+
 # ---- configs[2]: 1000 records of one geometry ----------------------------------------------------------------------------
 def test_c2_thousand_records_one_batch():
     from volumetricinterp_amd import synth

@@ -979,6 +979,12 @@ class FitEngine(object):
                 sub.ctx.close()
         self._subs = None
 
+    def __del__(self):
+        try:                                    # the contexts of the pipelines own streams and rocBLAS handles
+            self.close()
+        except Exception:
+            pass
+
     def close(self):
         self._close_subs()
         for b in self._bufs.values():
