@@ -655,8 +655,11 @@ class FitEngine(object):
             # walk values from the shared bases only decide signs; the bracket ends Brent starts from are asked for
             # again from cold solves (alpha_search.chi2_search_gen, refine)
             refine = bool(self._ref_rec is not None and self.shared_walk_enabled() and not cold)
+            # Brent's iteration on arrays pays from a dozen records on (NumPy's per-call overhead on arrays of one or two
+            # elements is several times the coroutine's step)
             alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
-                                                                   multisection=multisection, refine=refine)
+                                                                   multisection=multisection, refine=refine,
+                                                                   vector_brent=T >= 16)
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
