@@ -425,3 +425,25 @@ def test_vectorised_brent_takes_the_coroutines_steps():
     assert a1[0] == a2[0] and a1[1] == a2[1] and a1[3] == a2[3]
     for i1, i2 in zip(a1[2], a2[2]):
         assert i1 == i2
+
+
+def test_doubtful_walk_values_are_asked_for_together():
+    """A record whose chi^2 sits within the sign margin of a target over a long stretch of the walk (the 50 decades where
+    the systems are one and the same matrix, say) asks for their reference-grade values in one request, not decade by
+    decade - each request is a round of the evaluator - and ends where the exact function says."""
+    def exact_f(x):
+        if x <= -45.:
+            return 700. * (1. - 3e-3)            # just under nu = 0.7 * 1000: no root at sf = 0.7 but doubtful everywhere
+        return 400. + 500. / (1. + math.exp(-(x + 20.) * 1.5))
+
+    rounds = []
+
+    def ev(rec, la, exact=None):
+        ex = np.zeros(len(la), bool) if exact is None else np.asarray(exact)
+        rounds.append((len(la), int(ex.sum())))
+        return np.array([exact_f(x) * (1. if (e or x != math.floor(x)) else 1. + 1e-5 * math.sin(3. * x))
+                         for x, e in zip(la, ex)])
+    got = AS.run_batched([1000], ev, prefetch=8, refine=True)
+    clean = AS.run_batched([1000], lambda r, a: np.array([exact_f(x) for x in a]), prefetch=8)
+    assert got[0] == clean[0] and got[1] == clean[1]
+    assert sum(1 for _, nx in rounds if nx) <= 3, rounds          # doubtful decades in one or two requests + the bracket ends

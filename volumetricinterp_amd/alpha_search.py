@@ -21,6 +21,7 @@ import math
 import numpy as np
 
 SCALE_FACTORS = (0.6, 0.7, 0.8, 0.9, 1.0)      # interpolate.py:173
+DECADES = tuple(float(-k) for k in range(102))  # log10(alpha) of the bracket walk, interpolate.py:186-203
 XTOL = 2e-12
 RTOL = 4 * np.finfo(np.float64).eps
 MAXITER = 100
@@ -221,8 +222,12 @@ class Exact(tuple):
     __slots__ = ()
 
 
-# |chi^2 - nu| <= this fraction of nu at a walk point: the sign is not taken from an approximate walk value
-WALK_SIGN_MARGIN = 1e-3
+# |chi^2 - nu| <= this fraction of nu at a walk point: the sign is not taken from an approximate walk value.  Measured
+# (tools/exp_walk_floor.py, 1000 records x 49 decades of the BASELINE configs[2] geometry): the shared-basis chi^2 is within
+# 3e-4 of the cold one on 99.9 % of the systems, median 4e-9, 53 of 50 000 beyond 3e-4, one beyond 1e-3 (1.01e-3), none
+# beyond 3e-3 - next to the poles of chi^2(alpha), decades -28 and -33.  Five times the worst seen; it costs 1.7 extra cold
+# solves per record (0.4 at 1e-3, 3.5 at 1e-2).
+WALK_SIGN_MARGIN = 5e-3
 
 
 def chi2_search_gen(npts, multisection=0, refine=False, prefetch=1, defer_brent=False):
@@ -267,64 +272,95 @@ def chi2_search_gen(npts, multisection=0, refine=False, prefetch=1, defer_brent=
             walk[k] = v
         return walk[a]
 
+    cache_tab = [None, None]          # the trusted table and which of its entries are reference-grade
+
+    def walk_sf(sf, nu):
+        """The walk of one scale factor (interpolate.py:173-206): ('too_smooth' | 'bracket' | 'none', alpha, alpha0, val, val0).
+        Values are the reference-grade ones where known, the evaluator's plain ones otherwise; a plain value within the sign
+        margin of nu is not trusted: the walk is finished provisionally, ALL such decades are asked for as Exact in one
+        request, and the walk is done again (asking one at a time cost an evaluator round each)."""
+        while True:
+            pend = []
+            if len(walk) >= 102:
+                # the whole table is known (the first scale factor usually walks to the end without a bracket): the same walk
+                # in a few array operations instead of 102 interpreted steps
+                if cache_tab[0] is None:
+                    cache_tab[0] = np.array([memo_x[a] if a in memo_x else walk[a] for a in DECADES])
+                    cache_tab[1] = np.array([a in memo_x for a in DECADES])
+                tab, isx = cache_tab
+                v = tab - nu
+                entered = v[0] > 0                                  # val0 * val > 0 with val0 = 1
+                stops = np.nonzero(~(v[:-1] * v[1:] > 0))[0]
+                k = int(stops[0]) + 1 if len(stops) else 102        # first step whose product is not positive
+                last = min(k, 101) if entered else 0
+                if margin >= 0.:
+                    if np.any(~(np.abs(v[:last + 1]) > margin * nu) & ~isx[:last + 1]):
+                        # with the table complete, the doubtful decades of the later scale factors come along
+                        doubt = np.zeros(102, dtype=bool)
+                        for sf2 in SCALE_FACTORS:
+                            if sf2 >= sf:
+                                doubt |= ~(np.abs(tab - npts * sf2) > margin * npts * sf2)
+                        pend = [DECADES[j] for j in np.nonzero(doubt & ~isx)[0].tolist()]
+                if not pend:
+                    if v[0] < 0:
+                        return 'too_smooth', 0., 0., float(v[0]), 1.
+                    if entered and k <= 100:                        # the step to -101 ends the walk without a bracket
+                        return 'bracket', float(-k), float(-(k - 1)), float(v[k]), float(v[k - 1])
+                    return 'none', 0., 0., 0., 0.
+            else:
+                # (the look-ups of the walk are written out: a sub-generator per step cost more than the step)
+                kind = 'none'
+                alpha0, val0, alpha = 0., 1., 0.
+                c = memo_x.get(alpha)
+                if c is None:
+                    c = walk.get(alpha)
+                    if c is None:
+                        c = yield from fetch(alpha)
+                    if margin >= 0. and not abs(c - nu) > margin * nu:
+                        pend.append(alpha)
+                val = c - nu
+                if val < 0:
+                    kind = 'too_smooth'
+                else:
+                    entered = False
+                    while val0 * val > 0:
+                        entered = True
+                        val0 = val
+                        alpha0 = alpha
+                        alpha = alpha - 1.
+                        c = memo_x.get(alpha)
+                        if c is None:
+                            c = walk.get(alpha)
+                            if c is None:
+                                c = yield from fetch(alpha)
+                            if margin >= 0. and not abs(c - nu) > margin * nu:
+                                pend.append(alpha)
+                        val = c - nu
+                        if alpha < -100.:
+                            entered = False
+                            break
+                    if entered:
+                        kind = 'bracket'
+                if not pend:
+                    return kind, alpha, alpha0, val, val0
+            ks = tuple(pend)
+            for a, c in zip(ks, (yield Exact(ks))):
+                memo_x[a] = c
+            cache_tab[0] = None
+
     bracket = False
     alpha = alpha0 = 0.
     val = val0 = 1.
     sf_used = None
     nu = 0.
-    tab = None
     for sf in SCALE_FACTORS:
         nu = npts * sf
-        if len(walk) >= 102:
-            # the whole table is known (the first scale factor usually walks to the end without a bracket): the same
-            # walk in a few array operations instead of 102 interpreted steps
-            if tab is None:
-                tab = np.array([walk[float(-k)] for k in range(102)])
-            v = tab - nu
-            entered = v[0] > 0                                  # val0 * val > 0 with val0 = 1
-            stops = np.nonzero(~(v[:-1] * v[1:] > 0))[0]
-            k = int(stops[0]) + 1 if len(stops) else 102        # first step whose product is not positive
-            last = min(k, 101) if entered else 0
-            if not (margin >= 0. and bool(np.any(~(np.abs(v[:last + 1]) > margin * nu)))):
-                if v[0] < 0:
-                    return 'too_smooth', 0, dict(sf=sf)
-                if entered:
-                    bracket = k <= 100                          # the step to -101 ends the walk without a bracket
-                    if bracket:
-                        alpha, alpha0, val, val0 = float(-k), float(-(k - 1)), float(v[k]), float(v[k - 1])
-                if bracket:
-                    sf_used = sf
-                    break
-                continue
-        alpha0, val0, alpha = 0., 1., 0.
-        # (the two look-ups of the walk are written out: a sub-generator per step cost more than the step)
-        c = walk.get(alpha)
-        if c is None:
-            c = yield from fetch(alpha)
-        if margin >= 0. and not abs(c - nu) > margin * nu:           # too close to nu for a sign from an approximate value
-            c = memo_x.get(alpha)
-            if c is None:
-                c = memo_x[alpha] = (yield Exact((alpha,)))[0]
-        val = c - nu
-        if val < 0:
+        kind, a_, a0_, v_, v0_ = yield from walk_sf(sf, nu)
+        if kind == 'too_smooth':
             return 'too_smooth', 0, dict(sf=sf)
-        while val0 * val > 0:
+        if kind == 'bracket':
             bracket = True
-            val0 = val
-            alpha0 = alpha
-            alpha = alpha - 1.
-            c = walk.get(alpha)
-            if c is None:
-                c = yield from fetch(alpha)
-            if margin >= 0. and not abs(c - nu) > margin * nu:
-                c = memo_x.get(alpha)
-                if c is None:
-                    c = memo_x[alpha] = (yield Exact((alpha,)))[0]
-            val = c - nu
-            if alpha < -100.:
-                bracket = False
-                break
-        if bracket:
+            alpha, alpha0, val, val0 = a_, a0_, v_, v0_
             sf_used = sf
             break
     if not bracket:
