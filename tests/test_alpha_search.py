@@ -206,24 +206,6 @@ def test_search_with_multisection_on_smooth_chi2():
         assert nreq <= 4                            # 64^-4 < 1e-7: dependent rounds after the walk
 
 
-def test_run_brent_batched_matches_scipy():
-    """The batched Brent driver of the consistency guard's cold polish: same roots and iterate counts as scipy.optimize.brentq
-    on every bracket, whatever is batched together."""
-    import scipy.optimize
-    funcs = {0: (lambda x: (x - 0.3)**3 + 0.1 * (x - 0.3), 0., 1.), 3: (lambda x: math.cos(x) - x, 0., 1.),
-             7: (lambda x: math.exp(x) - 5., -1., 3.)}
-
-    def f_batch(rec, xs):
-        return np.array([funcs[int(r)][0](float(x)) for r, x in zip(rec, xs)])
-    br = {r: (a, b, f(a), f(b)) for r, (f, a, b) in funcs.items()}
-    out = AS.run_brent_batched(br, f_batch)
-    for r, (f, a, b) in funcs.items():
-        ref, info = scipy.optimize.brentq(f, a, b, full_output=True)
-        root, iters, other = out[r]
-        assert root == ref and iters == info.iterations
-        assert other is None or abs(other - root) <= 4e-12 + 1e-15
-
-
 def _literal_walk(chi2, npts):
     """interpolate.py:173-206 written out step by step (the bracket walk only): (outcome, sf, alpha, alpha0)."""
     bracket = False

@@ -531,30 +531,6 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
     return ([r[1] for r in results], [r[0] for r in results], [r[2] for r in results], nevals)
 
 
-def run_brent_batched(brackets, f_batch):
-    """Brent's iteration on given brackets, batched over records: brackets = {rec: (xa, xb, fa, fb)} with f values
-    (chi^2 - nu) of opposite sign; f_batch(rec array, x array) -> f array.  Returns {rec: (root, iterations, other_end)}."""
-    gens, pending, out = {}, {}, {}
-    for i, (xa, xb, fa, fb) in brackets.items():
-        g = brentq_gen(xa, xb, fa=fa, fb=fb)
-        try:
-            pending[i] = next(g)
-            gens[i] = g
-        except StopIteration as stop:
-            out[i] = (stop.value[0], stop.value[1], stop.value[3])
-    while gens:
-        rec = np.array(sorted(gens), dtype=np.int32)
-        xs = np.array([pending[int(i)] for i in rec], dtype=np.float64)
-        vals = f_batch(rec, xs)
-        for i, v in zip(rec.tolist(), vals):
-            try:
-                pending[i] = gens[i].send(float(v))
-            except StopIteration as stop:
-                out[i] = (stop.value[0], stop.value[1], stop.value[3])
-                del gens[i], pending[i]
-    return out
-
-
 POLISH_XTOL = 1e-7            # decades: a sign change confined to less than this without |f| getting small is a jump
 POLISH_BRENT_ROUNDS = 6
 

@@ -412,7 +412,6 @@ class FitEngine(object):
         # root-finder requests (non-integer): a record without a rotated system yet gets it from ONE of its
         # requests - the middle one when a multisection round asks for many, so the basis is nearest to all
         warm = np.zeros(B, dtype=bool)
-        prep = np.zeros(B, dtype=bool)
         rebase = np.zeros(B, dtype=bool)
         by_rec = {}
         for j in np.nonzero(~is_int & ~forced)[0].tolist():
@@ -456,8 +455,8 @@ class FitEngine(object):
         if len(w_idx) > 256 and os.environ.get('VINTERP_LPT', '1') != '0':
             dist = np.abs(log10a[w_idx] - np.array([self._basis_x.get(int(r), 0.) for r in rec[w_idx].tolist()]))
             w_idx = w_idx[np.argsort(-dist, kind='stable')]
-        order = np.concatenate([np.nonzero(cold)[0], sh_idx, np.nonzero(prep)[0], w_idx, np.nonzero(rebase)[0]])
-        nc, nsh, npre, nw, nrb = int(cold.sum()), len(sh_idx), int(prep.sum()), int(warm.sum()), int(rebase.sum())
+        order = np.concatenate([np.nonzero(cold)[0], sh_idx, w_idx, np.nonzero(rebase)[0]])
+        nc, nsh, nw, nrb = int(cold.sum()), len(sh_idx), int(warm.sum()), int(rebase.sum())
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
@@ -503,10 +502,6 @@ class FitEngine(object):
                                                    dbs.ptr, dal.offset_ptr(o), dV.ptr, dD2.ptr, EPS,
                                                    dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_basis_solve_f64')
             o += nsh
-        if npre:
-            self._warm_prepare('w_', self._warm_slot, rec_o[o:o + npre].tolist(), alpha_o[o:o + npre], name,
-                               dCall.offset_ptr(o * N), drank.offset_ptr(o))
-            o += npre
         if nw:
             self._warm_solve('w_', self._warm_slot, rec_o[o:o + nw], dal.offset_ptr(o), nw, dCall.offset_ptr(o * N),
                              drank.offset_ptr(o))
@@ -527,8 +522,8 @@ class FitEngine(object):
         out = np.empty(B)
         out[order] = tmp
         if trace:
-            print('[search round] B=%d cold=%d shared=%d prepare=%d warm=%d rebase=%d  %.2f ms  log10a[0]=%.12f' %
-                  (B, nc, nsh, npre, nw, nrb, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
+            print('[search round] B=%d cold=%d shared=%d warm=%d rebase=%d  %.2f ms  log10a[0]=%.12f' %
+                  (B, nc, nsh, nw, nrb, (time.perf_counter() - t_tr) * 1e3, log10a[0]))
         self.stats['solves'] += B
         self.stats['launches'] += 1
         self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nrb
