@@ -37,5 +37,10 @@ for t in range(T):
         worst = max(worst, miss)
     if i.get('walk_redone_exact'): cnt['walk redone exact'] += 1
 print('T=%d (first call, %.2f s): %s' % (T, t1 - t0, dict(cnt)))
+mv = np.array([abs(i['log10_alpha'] - i['warm_log10_alpha']) for i in inf['info'] if i.get('polished_cold')])
+if len(mv):
+    print('polished records: |log10 alpha - warm root| quantiles 10/50/90/100 %%: %s; polish rounds: median %d max %d' % (
+        np.quantile(mv, [0.1, 0.5, 0.9, 1.0]).tolist(), np.median([i['polish_iterations'] for i in inf['info'] if i.get('polished_cold')]),
+        max(i['polish_iterations'] for i in inf['info'] if i.get('polished_cold'))))
 print('largest |chi2 - nu| / nu among records not flagged as jumps: %.2e; Brent iterations: median %d, 90%% %d, max %d; stats %s'
       % (worst, np.median(its), np.quantile(its, 0.9), max(its), eng.stats))

@@ -676,7 +676,7 @@ extern "C" int vi_chi2_f64(vi_ctx* c, int64_t B, int64_t P, int32_t N, const dou
     if (rc != VI_OK) return rc;
     double* part = (double*)ws;
     // S systems share a block's loads of the basis; a system's arithmetic is the same for every S (see k_chi2_part)
-    if (B >= 2048) {
+    if (B >= 2048 && (size_t)(8 * N + 256) * sizeof(double) <= 48 * 1024) {          // (48 KB: the default LDS limit of a launch)
         hipLaunchKernelGGL((k_chi2_part<256, 8>), dim3(nblk(B, 8), nb), dim3(256), (size_t)(8 * N + 256) * sizeof(double),
                            c->stream, P, N, B, d_At, d_C, d_rec, (int64_t)0, d_W, d_b, part);
     } else if (B >= 256) {
