@@ -157,6 +157,41 @@ def test_pipelines_change_nothing_but_the_time(monkeypatch):
     eng.close()
 
 
+def test_largest_in_lds_order_goes_through_the_batched_search(monkeypatch):
+    """MAXK 5 x MAXL 6 (N = 180, the largest order the in-LDS solver takes; its rotated systems no longer fit the fused
+    form-and-scale kernel): a batch of 10 through the shared-basis walk, the re-basing and the guard - same answers as with
+    the walk solved cold, records 0 and 7 the same alone as in the batch, chi^2 on target or flagged."""
+    from volumetricinterp_amd import synth
+    cfg = CFG144.replace('MAXK = 4', 'MAXK = 5')
+    from volumetricinterp_amd.models.sphharmlag import Model
+    R = Model(io.StringIO(cfg)).eval_reg_matricies['curvature']()
+    m, ctx, eng, A, _ = _engine(cfg, synth.GEOM_C2, R=R)
+    assert A.shape[1] == 180
+    P, T = A.shape[0], 10
+    value, error = synth.synth_records(A, T, seed0=7000)
+    W = error**-2.
+    full = eng.fit(W, value, [P] * T)
+    assert eng.stats.get('shared_solves', 0) > 0 and eng.stats.get('rebased', 0) > 0
+    monkeypatch.setenv('VINTERP_SHAREDWALK', '0')
+    cold = eng.fit(W, value, [P] * T)
+    monkeypatch.delenv('VINTERP_SHAREDWALK')
+    assert np.array_equal(full['Coeffs'], cold['Coeffs'], equal_nan=True)
+    assert np.array_equal(full['chi_sq'], cold['chi_sq'], equal_nan=True)
+    for t in (0, 7):
+        one = eng.fit(W[t:t + 1], value[t:t + 1], [P])
+        assert np.array_equal(one['Coeffs'][0], full['Coeffs'][t], equal_nan=True), t
+    inf = full['search']['curvature']
+    nroot = 0
+    for t in range(T):
+        if inf['outcomes'][t] == 'root':
+            nroot += 1
+            nu = inf['info'][t]['sf'] * P
+            assert abs(full['chi_sq'][t] - nu) <= 1e-4 * nu or inf['info'][t].get('jump'), (t, full['chi_sq'][t], nu)
+            assert rel(A @ full['Coeffs'][t], value[t]) < 1.0
+    assert nroot >= 5
+    eng.close()
+
+
 # ---- configs[2]: 1000 records of one geometry ----------------------------------------------------------------------------
 def test_c2_thousand_records_one_batch():
     from volumetricinterp_amd import synth

@@ -62,13 +62,15 @@ __global__ void k_form_system(int NN, const double* __restrict__ AWA, const int*
 }
 
 // X[i] = D1[slot[i]] + alpha[i] * D2[slot[i]]   (warm-started search: both terms are per-record)
-__global__ void k_form_pair(int NN, const double* __restrict__ D1, const double* __restrict__ D2,
-                            const int* __restrict__ slot, const double* __restrict__ alpha, double* __restrict__ X)
+// slot1 null: D1[i] (X may then be D1 itself); slot2: where D2 of system i lives
+__global__ void k_form_pair(int NN, const double* D1, const double* __restrict__ D2, const int* __restrict__ slot1,
+                            const int* __restrict__ slot2, const double* __restrict__ alpha, double* X)
 {
     const int64_t i = blockIdx.x;
-    const int64_t w = slot[i];
+    const int64_t w1 = slot1 ? slot1[i] : i;
+    const int64_t w = slot2[i];
     const double a = alpha[i];
-    for (int e = threadIdx.x; e < NN; e += blockDim.x) X[i * NN + e] = fma(a, D2[w * NN + e], D1[w * NN + e]);
+    for (int e = threadIdx.x; e < NN; e += blockDim.x) X[i * NN + e] = fma(a, D2[w * NN + e], D1[w1 * NN + e]);
 }
 
 // out[i][k] = sum_r V[w][k*N + r] * v[src][r]      (V^T v; V in LAPACK eigenvector layout)
@@ -243,6 +245,20 @@ __global__ __launch_bounds__(BS) void k_form_pair_scaled(int NN, const double* D
         if (e < NN) X[i * NN + e] = v[u] * f;
     }
     if (tid == 0) scl[i] = 1.0 / f;      // exact (power of two)
+}
+
+// X[i] = f (D1[slot1[i]] + alpha[i] D2[slot2[i]]), scl[i] = 1 / f with f the power of two that brings max|X| into [1, 2):
+// one fused pass while a system fits the registers of a 1024-thread block (N <= 156), two kernels beyond
+static void form_pair_scaled(vi_ctx* c, int64_t bc, int NN, const double* D1, const double* D2, const int* slot1,
+                             const int* slot2, const double* alpha, double* X, double* scl)
+{
+    if (NN <= 24 * 1024) {
+        hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, D1, D2, slot1, slot2,
+                           alpha, X, scl);
+    } else {
+        hipLaunchKernelGGL(k_form_pair, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, D1, D2, slot1, slot2, alpha, X);
+        hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, X, scl);
+    }
 }
 
 // One workgroup per system: given eigenpairs (V column-major, lam) form the truncated minimum-norm
@@ -919,14 +935,7 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
     double* cp = X + (size_t)Bc * NN;
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
-        if (NN <= 24 * 1024) {
-            hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, d_D1, d_D2,
-                               d_slot + i0, d_slot + i0, d_alpha + i0, X, scl);
-        } else {
-            hipLaunchKernelGGL(k_form_pair, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_D1, d_D2, d_slot + i0,
-                               d_alpha + i0, X);
-            hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, X, scl);
-        }
+        form_pair_scaled(c, bc, NN, d_D1, d_D2, d_slot + i0, d_slot + i0, d_alpha + i0, X, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, d_slot + i0, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
                              JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
@@ -1042,13 +1051,7 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         VI_ROCBLAS(rocblas_dgemm_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, N, N, &one, pV, N,
                                          (const double* const*)pT, N, &zero, pD, N, (rocblas_int)bc));
         hipLaunchKernelGGL(k_vt_vec, dim3((unsigned)bc), dim3(256), 0, c->stream, N, d_V, d_basis + i0, d_y, d_rec + i0, yt);
-        if (NN <= 24 * 1024) {
-            hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, D1, d_D2,
-                               (const int*)nullptr, d_basis + i0, d_alpha + i0, D1, scl);
-        } else {
-            vi_set_error("vi_basis_solve_f64: N=%d too large for the fused system kernel", N);
-            return VI_ERR_UNSUPPORTED;
-        }
+        form_pair_scaled(c, bc, NN, D1, d_D2, nullptr, d_basis + i0, d_alpha + i0, D1, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, D1, scl, yt, nullptr, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
                              JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
@@ -1075,7 +1078,7 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double*
     VI_REQUIRE(c && d_AWA && d_R && d_y && d_rec && d_slot && d_alpha && d_V && d_D1 && d_D2 && d_yt && d_C, "null argument");
     VI_REQUIRE(B >= 0 && N > 0, "bad size");
     if (B == 0) return VI_OK;
-    if (!vi_jacobi_vectors_supported(N) || N * N > 24 * 1024) {
+    if (!vi_jacobi_vectors_supported(N)) {
         vi_set_error("vi_warm_rebase_f64: N=%d outside the in-LDS Jacobi range", N);
         return VI_ERR_UNSUPPORTED;
     }
@@ -1113,8 +1116,7 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
         const int32_t* slotc = d_slot + i0;
         const int32_t* recc = d_rec + i0;
-        hipLaunchKernelGGL((k_form_pair_scaled<1024, 24>), dim3((unsigned)bc), dim3(1024), 0, c->stream, NN, d_D1, d_D2, slotc,
-                           slotc, d_alpha + i0, X, scl);
+        form_pair_scaled(c, bc, NN, d_D1, d_D2, slotc, slotc, d_alpha + i0, X, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, slotc, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS,
                              nullptr, nullptr, 0, nrd, JACOBI_FLOOR_WARM);
