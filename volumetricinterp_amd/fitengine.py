@@ -11,7 +11,15 @@ Device-side engine behind ``Interpolate.calc_coeffs`` / ``eval_C`` /
   of once per trial alpha (the reference rebuilds them 367-491 times per record);
 * all (record, alpha) systems requested in one step of the search are formed,
   eigen-decomposed, truncated and scored in one batch
-  (``vi_form_system_f64`` -> ``vi_solve_trunc_f64`` -> ``vi_chi2_f64``).
+  (``vi_form_system_f64`` -> ``vi_solve_trunc_f64`` -> ``vi_chi2_f64``);
+* the systems of a search resemble each other, and the engine uses it (DESIGN.md
+  sections 4-5): Brent's iterates are solved in a rotated system of the record that
+  is moved next to the root once they cluster; a batch solves its bracket walk in
+  the eigenbases of one reference system per decade (values used for signs only,
+  the bracket ends come from cold solves); walk decades whose systems are one and
+  the same matrix are solved once; a record fitted alone decomposes the candidate
+  bracket bases in the launch of its walk; a big batch runs as concurrent pipelines.
+  None of this changes a record's numbers with the batch it is fitted in, bit for bit.
 """
 import ctypes as C
 import math
