@@ -280,21 +280,33 @@ class FitEngine(object):
         self._warm_slot = {}          # record -> slot of its Brent basis
         self._spec_slot = {}          # (record, bracket midpoint) -> slot of a basis decomposed alongside the walk
         self._last_x = {}             # record -> log10(alpha) of its previous root-finder request
-        self._rebased = set()         # records whose rotated system has been moved next to the root
+        self._rebased = {}            # record -> times its rotated system has been moved next to the root
+        self._nreq = {}               # record -> root-finder requests so far
         self._basis_x = {}            # record -> log10(alpha) its rotated system sits at
         self._basis_slot = {}         # decade -> slot of the reference system's eigenbasis (shared walk)
 
     REBASE_WITHIN = 3e-2          # decades between two consecutive root-finder requests of a record
+    REBASE_AGAIN_AFTER = 20
+    REBASE_AGAIN_WITHIN = 1e-5
 
     def _wants_rebase(self, r, x):
         """Brent's iterates have started to cluster (this request lies within REBASE_WITHIN decades of the record's previous
         one) and the record's rotated system still sits at the middle of the bracket: move it here, once
         (vi_warm_rebase_f64).  The rule looks at the record's own requests only, so what a record sees does not depend on
         the batch it is in."""
-        if r in self._rebased or os.environ.get('VINTERP_REBASE', '1') == '0':
+        if os.environ.get('VINTERP_REBASE', '1') == '0':
             return False
         last = self._last_x.get(r)
-        return last is not None and abs(x - last) < self.REBASE_WITHIN
+        if last is None:
+            return False
+        done = self._rebased.get(r, 0)
+        if done == 0:
+            return abs(x - last) < self.REBASE_WITHIN
+        # a second time for the records that are still iterating after REBASE_AGAIN_AFTER requests: they sit on a jump of
+        # chi^2 (an eigenvalue of X(alpha) at the cut), Brent bisects down to 2e-12 in 40-60 steps there, and from a basis
+        # 1e-3 decades away those solves take 13 sweeps each
+        return (done == 1 and self._nreq.get(r, 0) >= self.REBASE_AGAIN_AFTER and abs(x - last) < self.REBASE_AGAIN_WITHIN
+                and os.environ.get('VINTERP_REBASE2', '1') != '0')
 
     def _warm_buffers(self, tag):
         T, N = self.T, self.N
@@ -392,6 +404,7 @@ class FitEngine(object):
         if (B == 1 and not is_int[0] and not forced[0] and self.warm_enabled() and int(rec[0]) in self._warm_slot
                 and not self._wants_rebase(int(rec[0]), float(log10a[0]))):
             self._last_x[int(rec[0])] = float(log10a[0])
+            self._nreq[int(rec[0])] = self._nreq.get(int(rec[0]), 0) + 1
             # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
             scratch = self._buf('w_one', (N + 8,))
@@ -432,9 +445,10 @@ class FitEngine(object):
                 if r in self._warm_slot and self._wants_rebase(r, x):
                     warm[js] = False
                     rebase[js] = True
-                    self._rebased.add(r)
+                    self._rebased[r] = self._rebased.get(r, 0) + 1
                     self._basis_x[r] = x
                 self._last_x[r] = x
+                self._nreq[r] = self._nreq.get(r, 0) + 1
             if r not in self._warm_slot:
                 # The rotated system of a record is set up at the MIDDLE of its unit bracket, 10^(floor(x) + 1/2),
                 # whatever the request that triggers it (Brent's first iterate, a multisection sample): the warm chi^2 is
