@@ -1,4 +1,5 @@
-"""A/B of the bracket walk in shared bases (VINTERP_SHAREDWALK): time and answers of a batched fit, both ways.
+"""A/B of the bracket walk in shared bases (VINTERP_SHAREDWALK): time and answers of a batched fit, both ways
+(MODES=c1: "c" or "0" = every walk system solved cold, "1" = shared bases).
 Usage (GPU): python tools/exp_sharedwalk_ab.py [T]"""
 import io, os, sys, time
 import numpy as np
@@ -19,7 +20,6 @@ value, error = synth.synth_records(A, T, seed0=1000)
 res = {}
 for mode in tuple(os.environ.get('MODES', '01')):
     os.environ['VINTERP_SHAREDWALK'] = '1' if mode == '1' else '0'
-    os.environ['VINTERP_WALKWARM'] = '0' if mode == 'c' else '1'          # 'c': every walk system solved cold
     eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
     eng.upload_records(error**-2., value)
     eng.fit_resident([P] * T, calccov=True)
