@@ -221,9 +221,10 @@ int  vi_warm_finish_f64(vi_ctx* ctx, int64_t B, int32_t N, const void* d_log, co
 /* vi_warm_solve_f64 for B (slot, record, alpha) triples that also MOVES each slot's rotated system to alpha: the
  * eigenvectors of the rotated system come out of the rotation log, V <- V Vw, and D1, D2, yt are formed again from the
  * untransformed AWA[rec], R, y[rec].  Brent's late iterates (interpolate.py:214) sit within 1e-3 decades of each other;
- * from a basis that close a warm solve takes 1-3 sweeps instead of 6-13.  A slot may appear once per call. */
-int  vi_warm_rebase_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const double* d_R, const double* d_y,
-                        const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
+ * from a basis that close a warm solve takes 1-3 sweeps instead of 6-13.  A slot may appear once per call.  The first
+ * nplain triples are plain warm solves (no re-basing) that share the eigen-solve launch of the others. */
+int  vi_warm_rebase_f64(vi_ctx* ctx, int64_t B, int64_t nplain, int32_t N, const double* d_AWA, const double* d_R,
+                        const double* d_y, const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
                         double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank);
 
 /* out[t] = the alpha below which alpha R vanishes from AWA[t] + alpha R in floating point (alpha |R_ij| under a quarter

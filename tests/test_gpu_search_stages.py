@@ -166,9 +166,16 @@ def test_rebase_moves_the_rotated_system_and_keeps_the_solution(setup):
     _lib.check(_lib.lib.vi_warm_solve_f64(h, B, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot.ptr, dal.ptr, EPS, dCw.ptr, drk.ptr),
                'warm')
     dCr = ctx.empty((B, N))
-    _lib.check(_lib.lib.vi_warm_rebase_f64(h, B, N, eng.dAWA.ptr, eng.R['curvature'].ptr, eng.dy.ptr, drec.ptr, slot.ptr, dal.ptr,
+    # record 0 rides along as a plain warm solve (nplain = 1): its rotated system must stay where it is
+    keep0 = [x.download()[0].copy() for x in (dV, dD1, dD2, dyt)]
+    _lib.check(_lib.lib.vi_warm_rebase_f64(h, B, 1, N, eng.dAWA.ptr, eng.R['curvature'].ptr, eng.dy.ptr, drec.ptr, slot.ptr, dal.ptr,
                                            EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr), 'rebase')
-    assert np.array_equal(dCr.download(), dCw.download())          # the solution returned is the warm solve's
+    assert np.array_equal(dCr.download(), dCw.download())          # the solutions returned are the warm solve's
+    for a, b in zip(keep0, (dV, dD1, dD2, dyt)):
+        assert np.array_equal(a, b.download()[0])
+    # now all three re-base (record 0 too)
+    _lib.check(_lib.lib.vi_warm_rebase_f64(h, B, 0, N, eng.dAWA.ptr, eng.R['curvature'].ptr, eng.dy.ptr, drec.ptr, slot.ptr, dal.ptr,
+                                           EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr), 'rebase')
     V, D1, D2, yt = dV.download(), dD1.download(), dD2.download(), dyt.download()
     for i, t in enumerate(rec):
         Vm = V[i].T                                               # columns = basis vectors

@@ -1071,13 +1071,18 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
 // system come out of the rotation log, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V, yt = V^T y are formed again from the
 // untransformed matrices (no compounding of the transform's rounding).  One warm solve + the eigenvector replay + six
 // small products instead of a cold decomposition.
-extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const double* d_R, const double* d_y,
-                                  const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
-                                  double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank)
+// nplain > 0: the first nplain triples are plain warm solves (vi_warm_solve_f64) that ride in the same eigen-solve launch -
+// a round of Brent's iteration of a batch has both kinds, and a launch lasts as long as its slowest system whether it holds
+// 30 systems or 250.
+extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t N, const double* d_AWA, const double* d_R,
+                                  const double* d_y, const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha,
+                                  double rcond, double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C,
+                                  int32_t* d_rank)
 {
     VI_REQUIRE(c && d_AWA && d_R && d_y && d_rec && d_slot && d_alpha && d_V && d_D1 && d_D2 && d_yt && d_C, "null argument");
-    VI_REQUIRE(B >= 0 && N > 0, "bad size");
+    VI_REQUIRE(B >= 0 && N > 0 && nplain >= 0 && nplain <= B, "bad size");
     if (B == 0) return VI_OK;
+    if (nplain == B) return vi_warm_solve_f64(c, B, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank);
     if (!vi_jacobi_vectors_supported(N)) {
         vi_set_error("vi_warm_rebase_f64: N=%d outside the in-LDS Jacobi range", N);
         return VI_ERR_UNSUPPORTED;
@@ -1089,6 +1094,13 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double*
                        8 * sizeof(void*);
     int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
     if (Bc < 1) Bc = 1;
+    if (nplain > 0 && B > Bc) {
+        // more than one workspace chunk: the plain solves on their own, then the re-basing ones
+        int rc0 = vi_warm_solve_f64(c, nplain, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank);
+        if (rc0 != VI_OK) return rc0;
+        return vi_warm_rebase_f64(c, B - nplain, 0, N, d_AWA, d_R, d_y, d_rec + nplain, d_slot + nplain, d_alpha + nplain, rcond,
+                                  d_V, d_D1, d_D2, d_yt, d_C + nplain * N, d_rank ? d_rank + nplain : nullptr);
+    }
     if (Bc > B) Bc = B;
     const int64_t Bcp = group_pad(Bc);
     void* ws = nullptr;
@@ -1113,7 +1125,7 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double*
     const double** pVslot = pD2 + Bcp;
     int* nrd = (int*)(pVslot + Bcp);
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
-        const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
+        int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
         const int32_t* slotc = d_slot + i0;
         const int32_t* recc = d_rec + i0;
         form_pair_scaled(c, bc, NN, d_D1, d_D2, slotc, slotc, d_alpha + i0, X, scl);
@@ -1124,8 +1136,13 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V, slotc, cp,
                            d_C + i0 * N);
         VI_HIP(hipGetLastError());
-        rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, Vw);
+        // from here on only the systems that re-base (nplain > 0 implies a single chunk, i0 = 0)
+        const int64_t skip = i0 == 0 ? nplain : 0;
+        rc = vi_jacobi_vectors(c, bc - skip, N, (const char*)ws + (size_t)skip * logb, JACOBI_MAX_SWEEPS, nrd + skip, Vw);
         if (rc != VI_OK) return rc;
+        slotc += skip;
+        recc += skip;
+        bc -= skip;
         // V_new = V_old Vw (into Vn, then back into the slots), then the rotated system from the untransformed matrices
         if ((rc = group_ptrs(c, bc, d_V, NN, nullptr, 0, pVold, slotc)) != VI_OK) return rc;
         if ((rc = group_ptrs(c, bc, Vw, NN, scrA, NN, pVw)) != VI_OK) return rc;

@@ -53,7 +53,7 @@ _lib._sig('vi_decompose_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VO
           _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_finish_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
-_lib._sig('vi_warm_rebase_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+_lib._sig('vi_warm_rebase_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_chi2_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.c_int32, C.c_double, C.c_double, _lib.VOIDP, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
@@ -524,15 +524,17 @@ class FitEngine(object):
                                                    dbs.ptr, dal.offset_ptr(o), dV.ptr, dD2.ptr, EPS,
                                                    dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_basis_solve_f64')
             o += nsh
-        if nw:
+        if nw and not nrb:
             self._warm_solve('w_', self._warm_slot, rec_o[o:o + nw], dal.offset_ptr(o), nw, dCall.offset_ptr(o * N),
                              drank.offset_ptr(o))
-            o += nw
-        if nrb:
+        elif nrb:
+            # the plain warm solves of the round ride in the launch of the re-basing ones (a launch lasts as long as its
+            # slowest system, however few it holds)
+            n = nw + nrb
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
-            sl = np.array([self._warm_slot[int(r)] for r in rec_o[o:o + nrb]], dtype=np.int32)
-            dslot = self._buf('w_rbslot', (nrb,), np.int32).upload(sl)
-            _lib.check(_lib.lib.vi_warm_rebase_f64(h, nrb, N, self.dAWA.ptr, self.R[name].ptr, self.dy.ptr, drec.offset_ptr(o),
+            sl = np.array([self._warm_slot[int(r)] for r in rec_o[o:o + n]], dtype=np.int32)
+            dslot = self._buf('w_rbslot', (n,), np.int32).upload(sl)
+            _lib.check(_lib.lib.vi_warm_rebase_f64(h, n, nw, N, self.dAWA.ptr, self.R[name].ptr, self.dy.ptr, drec.offset_ptr(o),
                                                    dslot.ptr, dal.offset_ptr(o), EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr,
                                                    dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_warm_rebase_f64')
             self.stats['rebased'] = self.stats.get('rebased', 0) + nrb
