@@ -498,6 +498,12 @@ class FitEngine(object):
         if nsh:
             decades = np.rint(log10a[sh_idx]).astype(np.int64)
             new_k = sorted(set(decades.tolist()) - set(self._basis_slot), reverse=True)
+            if new_k and not self._basis_slot:
+                # the reference bases of ALL the decades the walk can ask for, in one launch: decade by decade as the walk
+                # proceeds, every round waited for its own cold decompositions (3.5 ms + eigenvectors, seven times)
+                kfl = self._same_below.get(name)
+                lowest = int(max(-101, np.min(kfl))) if kfl is not None and len(kfl) else -101
+                new_k = sorted(set(new_k) | set(range(0, min(lowest, min(new_k)) - 1, -1)), reverse=True)
             dV, dD1, dD2, dyt = (self._buf('sb_V', (102, N, N)), self._buf('sb_D1', (102, N, N)),
                                  self._buf('sb_D2', (102, N, N)), self._buf('sb_yt', (102, N)))
             if new_k:
