@@ -729,12 +729,18 @@ int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sw
     // so that a system's rotation log is read N / 8 times (throughput).  The strips of one system are neighbours in the
     // grid (x fastest), so they read its log together through L2.
     const int64_t log_stride = jacobi_log_stride(N, max_sweeps);
-    if (B * N <= 2 * c->n_cu)
-        hipLaunchKernelGGL(k_jacobi_vectors_wave<1>, dim3((unsigned)N, (unsigned)B), dim3(64), 0, c->stream, N,
-                           (const double2*)d_log, log_stride, d_nround, d_V);
-    else
-        hipLaunchKernelGGL(k_jacobi_vectors_wave<8>, dim3((unsigned)((N + 7) / 8), (unsigned)B), dim3(64), 0, c->stream, N,
-                           (const double2*)d_log, log_stride, d_nround, d_V);
+    // columns per wave: as few as keeps ~8 waves per CU busy (a wave with 8 columns takes 8 times as long as one with 1;
+    // the handful of systems of a re-basing round waited 1.2-2.9 ms for 18 waves per system while the chip stood empty).
+    // All instances do the same arithmetic per column (WaveReplay::inv), so the choice does not show in the result.
+    const int64_t cols = B * N, target = (int64_t)8 * c->n_cu;
+#define VI_VEC(CPW)                                                                                                           \
+    hipLaunchKernelGGL(k_jacobi_vectors_wave<CPW>, dim3((unsigned)((N + CPW - 1) / CPW), (unsigned)B), dim3(64), 0, c->stream, \
+                       N, (const double2*)d_log, log_stride, d_nround, d_V)
+    if (cols <= target) VI_VEC(1);
+    else if (cols <= 2 * target) VI_VEC(2);
+    else if (cols <= 4 * target) VI_VEC(4);
+    else VI_VEC(8);
+#undef VI_VEC
     VI_HIP(hipGetLastError());
     return VI_OK;
 }
