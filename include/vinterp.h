@@ -271,6 +271,13 @@ int  vi_rccl_destroy(vi_ctx* ctx);
  * vi_solve_trunc_f64 uses, and the sweeps each system needed.  d_X is rescaled in place. */
 int  vi_eigvals_f64(vi_ctx* ctx, int64_t B, int32_t N, double* d_X, double* d_lam, int32_t* d_sweeps);
 
+/* Stage-test entry of the pre-conditioner of the cold solves (csrc/vi_qr.hip): one column-pivoted Householder QR step
+ * X P = Q R of each of B symmetric systems, returned as the similar matrix X1 = Q^T X Q (same eigenvalues; the matrix
+ * the Jacobi kernel then iterates on), y1 = Q^T y and the explicit Q (Q[:, j] contiguous).  The solve it serves is
+ * scipy.linalg.lstsq at interpolate.py:462; d_X is only read. */
+int  vi_qr_similarity_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_X, const double* d_y, double* d_X1,
+                          double* d_y1, double* d_Q);
+
 #ifdef __cplusplus
 }
 #endif

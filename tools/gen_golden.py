@@ -377,6 +377,87 @@ def gen_default_many(workdir):
         save('fit_' + tag, **out)
 
 
+ROOTS_SEEDS = tuple(range(100, 116))
+
+
+def _roots_worker(job):
+    """One perturbed reference run (all records of one geometry); returns plain arrays."""
+    tag, geom, T, seed0, perturb, workdir = job
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from volumetricinterp.estimate import Estimate
+    regs = np.load(os.path.join(GOLD, 'regmat.npz'))
+    R = regs['default_curvature']
+    cfg = config_text(reglist='curvature', maxk=4, maxl=6, cap=10)
+    m = ref_model(cfg)
+    g = synth.query_grid(8)
+    lat, lon, alt = synth.beams(*geom, seed=0)
+    A = m.basis(lat, lon, alt)
+    value, error = synth.synth_records(A, T, seed0=seed0)
+    utime = synth.unix_times(T)
+    it, rec = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, {'curvature': R}, perturb=perturb)
+    alphas = np.array([rp['curvature'] for rp in rec.reg_params[:T]], dtype=np.float64)
+    es = Estimate.__new__(Estimate)
+    es.timetol, es.timeinterp = 60., False
+    es.Coeffs, es.Covariance, es.time, es.hull_vert = it.Coeffs, it.Covariance, utime, it.hull_vert
+    es.model = m
+    dens = []
+    for t in range(T):
+        if not np.all(np.isfinite(it.Coeffs[t])):
+            dens.append(np.full(g[0].shape, np.nan))
+            continue
+        t_mid = dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(np.mean(utime[t])))
+        dens.append(es(t_mid, *g, check_hull=True))
+    # split the chi2objfunct log by record (a record starts at alpha = 0 with nu = 0.6 npts) and keep, per record,
+    # the target nu of its last call and the walk table chi2(10^a), a = 0, -1, ... (the same for every scale factor)
+    npts = np.isfinite(value).sum(axis=1)
+    calls = np.array(rec.chi2_calls)
+    nu_last, walk, nbrent, tt, ncall = [], np.full((T, 102), np.nan), np.zeros(T, dtype=np.int64), -1, 0
+    for a_, nu_, v_ in calls:
+        if a_ == 0.0 and tt + 1 < T and abs(nu_ - 0.6 * npts[tt + 1]) < 1e-9 and (tt < 0 or ncall > 0):
+            tt += 1
+            nu_last.append(nu_)
+            ncall = 0
+        nu_last[tt] = nu_
+        ncall += 1
+        if a_ == np.round(a_) and -101 <= a_ <= 0:
+            walk[tt, int(-a_)] = v_ + nu_
+        else:
+            nbrent[tt] += 1
+    return dict(tag=tag, perturb=perturb, alpha=alphas, Coeffs=it.Coeffs, chi_sq=it.chi_sq, dens=np.array(dens),
+                nu=np.array(nu_last), walk=walk, nbrent=nbrent)
+
+
+def gen_default_roots(workdir):
+    """The reference's *root set* at the default order (N = 144): each record of fit_default16 (11 x 50, 16 records) and
+    fit_default_c2 (26 x 100, 4 records) is fitted by the reference again in 16 runs, each with its own 1e-14 relative
+    noise on the basis (seeds ROOTS_SEEDS).  Per run and record: alpha, the chi^2 target nu = scale factor x points, the
+    final chi^2, the walk table chi^2(10^a) the run saw, the coefficients and the densities on the 8^3 query grid.
+    tests/test_gpu_default_order.py measures the build against these sets (which brackets and roots the reference
+    itself reaches, and how far its runs at one root scatter)."""
+    import multiprocessing as mp
+    jobs = []
+    for tag, geom, T, seed0 in [('default_c2', synth.GEOM_C2, 4, 1000), ('default16', synth.GEOM_C1, 16, 6000)]:
+        for s in ROOTS_SEEDS:
+            jobs.append((tag, geom, T, seed0, s, workdir))
+    nproc = int(os.environ.get('VI_GOLD_PROCS', '7'))
+    with mp.get_context('fork').Pool(nproc) as pool:
+        res = []
+        for r in pool.imap_unordered(_roots_worker, jobs):
+            res.append(r)
+            print(r['tag'], 'seed', r['perturb'], 'log10 alpha',
+                  np.round(np.log10(np.where(r['alpha'] > 0, r['alpha'], np.nan)), 4), flush=True)
+    out = dict(seeds=np.array(ROOTS_SEEDS))
+    for tag in ('default_c2', 'default16'):
+        rs = sorted([r for r in res if r['tag'] == tag], key=lambda r: r['perturb'])
+        for k in ('alpha', 'Coeffs', 'chi_sq', 'dens', 'nu', 'walk', 'nbrent'):
+            out[tag + '_' + k] = np.array([r[k] for r in rs])
+    save('fit_default_roots', **out)
+
+
 def gen_grad(workdir):
     """grad_basis (sphharmlag.py:148-184): advertised by the reference, never called by its own workflow."""
     out = {}
@@ -480,7 +561,7 @@ def main():
     setup_reference(args.ref)
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
     steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval),
-             ('default_many', gen_default_many)]
+             ('default_many', gen_default_many), ('default_roots', gen_default_roots)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue

@@ -22,9 +22,17 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps);
 bool vi_jacobi_supported(int N);
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor);
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride = 0);
 bool vi_jacobi_vectors_supported(int N);
-int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V);
+int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V,
+                      int64_t log_stride = 0);
+// K3p (vi_qr.hip): X1 = Q^T X Q, y1 = Q^T y by one column-pivoted Householder QR step; back-transformations c <- Q c
+bool vi_qr_supported(int N);
+size_t vi_qr_hh_bytes(int N);
+int vi_qr_precond(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_y, const int* d_rec, double* d_X1,
+                  double* d_y1, double* d_hh, double* d_scr, int64_t hh_stride = 0);
+int vi_qr_back_vec(vi_ctx* c, int64_t B, int N, const double* d_hh, double* d_C, int64_t hh_stride = 0);
+int vi_qr_back_mat(vi_ctx* c, int64_t B, int N, const double* d_hh, double* d_V, int64_t hh_stride = 0);
 
 namespace {
 
@@ -464,6 +472,20 @@ double jacobi_floor_warm()
 }
 #define JACOBI_FLOOR_WARM jacobi_floor_warm()
 
+// K3p: the cold solves (walk ends, bracket bases, final solves - everything that starts from X(alpha) itself) are
+// pre-conditioned by one pivoted-QR similarity step (vi_qr.hip): 5-8 Jacobi sweeps instead of 20-24 at the default order.
+// VINTERP_QRPRE=0 switches it off.  The rotated systems of the warm / shared-basis solves are nearly diagonal already.
+bool qr_enabled(int N)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VINTERP_QRPRE");
+        v = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    return v == 1 && vi_qr_supported(N);
+}
+inline size_t up16(size_t b) { return (b + 15) & ~(size_t)15; }
+
 }  // namespace
 
 namespace {
@@ -578,35 +600,51 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
     VI_HIP(hipSetDevice(c->device));
     if (!d_H && eig_method() == 2 && vi_jacobi_supported(N)) {
         // in-LDS Jacobi: chunk the batch so that the rotation logs stay within 4 GiB of workspace
+        const bool qr = qr_enabled(N);
         const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
-        int64_t Bc = (int64_t)(((size_t)4 << 30) / logb);
+        const size_t hhb = qr ? up16(vi_qr_hh_bytes(N)) : 0;
+        const size_t per = logb + sizeof(double) + (qr ? hhb + (size_t)(N * N + N) * sizeof(double) : 0);
+        int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
         if (Bc < 1) Bc = 1;
         if (Bc > B) Bc = B;
         void* ws = nullptr;
-        int rc = vi_ctx_workspace(c, (size_t)Bc * logb + (size_t)Bc * sizeof(double) + 256, &ws);
+        int rc = vi_ctx_workspace(c, (size_t)Bc * per + 256, &ws);
         if (rc != VI_OK) return rc;
         double* scl = (double*)((char*)ws + (size_t)Bc * logb);
+        double* hh = scl + Bc + (Bc & 1);
+        double* scr = (double*)((char*)hh + (size_t)Bc * hhb);
+        double* y1 = scr + (size_t)Bc * N * N;
         for (int64_t i0 = 0; i0 < B; i0 += Bc) {
             const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
             double* Xc = d_X + i0 * N * N;
+            const double* yc = d_rec ? d_y : d_y + i0 * N;
+            const int* rcc = d_rec ? d_rec + i0 : nullptr;
             hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
             VI_HIP(hipGetLastError());
-            rc = vi_jacobi_solve(c, bc, N, Xc, scl, d_rec ? d_y : d_y + i0 * N, d_rec ? d_rec + i0 : nullptr, rcond,
-                                 d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, nullptr, 0,
-                                 nullptr, JACOBI_FLOOR_COLD);
+            if (qr) {
+                if ((rc = vi_qr_precond(c, bc, N, Xc, yc, rcc, Xc, y1, hh, scr, (int64_t)(hhb / 8))) != VI_OK) return rc;
+                yc = y1;
+                rcc = nullptr;
+            }
+            rc = vi_jacobi_solve(c, bc, N, Xc, scl, yc, rcc, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
+                                 JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_COLD);
             if (rc != VI_OK) return rc;
+            if (qr && (rc = vi_qr_back_vec(c, bc, N, hh, d_C + i0 * N, (int64_t)(hhb / 8))) != VI_OK) return rc;
         }
         return VI_OK;
     }
     if (d_H && eig_method() == 2 && vi_jacobi_vectors_supported(N)) {
         // final solves with H = pinv(X): in-LDS Jacobi (C, eigenvalues, rotation log) -> eigenvectors from the
         // log -> H = V diag(1/lam | kept) V^T
+        const bool qr = qr_enabled(N);
         const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+        const size_t hhb = qr ? up16(vi_qr_hh_bytes(N)) : 0;
         int64_t Bc = (int64_t)(((size_t)4 << 30) / logb);
         if (Bc < 1) Bc = 1;
         if (Bc > B) Bc = B;
         void* ws = nullptr;
-        const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * N * N * sizeof(double);
+        const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * N * N * sizeof(double) +
+                           (qr ? hhb + (size_t)N * sizeof(double) : 0);
         int rc = vi_ctx_workspace(c, (size_t)Bc * per + 1024, &ws);
         if (rc != VI_OK) return rc;
         char* wp = (char*)ws + (size_t)Bc * logb;
@@ -614,7 +652,9 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
         double* lam = scl + Bc;
         double* V = lam + (size_t)Bc * N;
         double* Vs = V + (size_t)Bc * N * N;
-        int* nrd = (int*)(Vs + (size_t)Bc * N * N);
+        double* y1 = Vs + (size_t)Bc * N * N;
+        double* hh = y1 + (qr ? (size_t)Bc * N : 0);
+        int* nrd = (int*)((char*)hh + (size_t)Bc * hhb);
         const double one = 1.0, zero = 0.0;
         for (int64_t i0 = 0; i0 < B; i0 += Bc) {
             const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
@@ -623,11 +663,15 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
             const int* rc_ = d_rec ? d_rec + i0 : nullptr;
             hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, N * N, Xc, scl);
             VI_HIP(hipGetLastError());
-            rc = vi_jacobi_solve(c, bc, N, Xc, scl, yc, rc_, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, ws,
-                                 JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd, JACOBI_FLOOR_COLD);
+            // pre-conditioned: the Jacobi kernel works on X1 = Q^T X Q (Vs is free until k_trunc_apply: QR scratch);
+            // its eigenvectors are turned back, V = Q V1, and k_trunc_apply then sees X's own eigenpairs and y
+            if (qr && (rc = vi_qr_precond(c, bc, N, Xc, yc, rc_, Xc, y1, hh, Vs, (int64_t)(hhb / 8))) != VI_OK) return rc;
+            rc = vi_jacobi_solve(c, bc, N, Xc, scl, qr ? y1 : yc, qr ? nullptr : rc_, rcond, d_C + i0 * N,
+                                 d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd, JACOBI_FLOOR_COLD);
             if (rc != VI_OK) return rc;
             rc = vi_jacobi_vectors(c, bc, N, ws, JACOBI_MAX_SWEEPS, nrd, V);
             if (rc != VI_OK) return rc;
+            if (qr && (rc = vi_qr_back_mat(c, bc, N, hh, V, (int64_t)(hhb / 8))) != VI_OK) return rc;
             constexpr int BS = 256;
             hipLaunchKernelGGL(k_trunc_apply<BS>, dim3((unsigned)bc), dim3(BS), (size_t)(N + BS) * sizeof(double), c->stream,
                                N, V, lam, scl, yc, rc_, rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, pinv_rcond, Vs);
@@ -740,16 +784,24 @@ extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, doub
         return VI_ERR_UNSUPPORTED;
     }
     VI_HIP(hipSetDevice(c->device));
+    const bool qr = qr_enabled(N);
     const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
+    const size_t hhb = qr ? up16(vi_qr_hh_bytes(N)) : 0;
     void* ws = nullptr;
-    int rc = vi_ctx_workspace(c, (size_t)B * logb + (size_t)B * (N + 1) * sizeof(double) * 2 + 256, &ws);
+    int rc = vi_ctx_workspace(c, (size_t)B * logb + (size_t)B * (N + 1) * sizeof(double) * 3 + 256 +
+                                     (qr ? (size_t)B * (hhb + (size_t)N * N * sizeof(double)) : 0), &ws);
     if (rc != VI_OK) return rc;
     double* scl = (double*)((char*)ws + (size_t)B * logb);
-    double* yz = scl + B;            // zero right-hand sides
+    double* yz = scl + B + (B & 1);  // zero right-hand sides
     double* Cz = yz + (size_t)B * N;
+    double* y1 = Cz + (size_t)B * N;
+    double* hh = y1 + (size_t)B * N + ((B * N) & 1);
+    double* scr = (double*)((char*)hh + (size_t)B * hhb);
     VI_HIP(hipMemsetAsync(yz, 0, (size_t)B * N * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)B), dim3(256), 0, c->stream, N * N, d_X, scl);
     VI_HIP(hipGetLastError());
+    // the same pre-conditioning as vi_solve_trunc_f64 (X1 = Q^T X Q has X's eigenvalues)
+    if (qr && (rc = vi_qr_precond(c, B, N, d_X, yz, nullptr, d_X, y1, hh, scr, (int64_t)(hhb / 8))) != VI_OK) return rc;
     return vi_jacobi_solve(c, B, N, d_X, scl, yz, nullptr, 2.220446049250313e-16, Cz, nullptr, ws,
                            JACOBI_MAX_SWEEPS, d_sweeps, d_lam, 0, nullptr, JACOBI_FLOOR_COLD);
 }
@@ -760,18 +812,34 @@ extern "C" int vi_eigvals_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, doub
 // D1 = V^T AWA V, D2 = V^T R V, yt = V^T y are formed; every later iterate then solves the rotated system
 // D1 + alpha D2 (3-10 Jacobi sweeps instead of 17-24 in the rank-deficient regime) and maps back C = V c'.
 namespace {
-// phase 1 of setting up rotated systems: X(alpha0) of bc records formed, scaled and decomposed (cold), the truncated solution
-// to Cc, the rotation logs to `log`, the rounds they hold to nrd
+// Rotation logs of systems that are decomposed now and turned into eigenvectors later lie in records of
+// log_record_bytes(N): the log itself, then (pre-conditioned solves) the Householder reflectors of the system's QR step.
+size_t log_record_bytes(int N)
+{
+    return vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS) + (qr_enabled(N) ? up16(vi_qr_hh_bytes(N)) : 0);
+}
+
+// phase 1 of setting up rotated systems: X(alpha0) of bc records formed, scaled, pre-conditioned (y1, scr: N and N x N
+// doubles of scratch per system) and decomposed (cold), the truncated solution to Cc, the rotation logs (+ reflectors) to
+// the records at `log`, the rounds they hold to nrd
 int prep_decompose(vi_ctx* c, int64_t bc, int N, const double* d_AWA, const int32_t* recc, const double* alpha0c,
                    const double* d_R, const double* d_y, double rcond, double* Cc, int32_t* rankc, void* log, double* scl,
-                   double* lam, double* T0, int* nrd)
+                   double* lam, double* T0, int* nrd, double* y1, double* scr)
 {
     const int NN = N * N;
+    const bool qr = qr_enabled(N);
+    const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS), recb = log_record_bytes(N);
+    double* hh = (double*)((char*)log + logb);
     hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, alpha0c, d_R, T0);
     hipLaunchKernelGGL(k_scale_system<256>, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, T0, scl);
     VI_HIP(hipGetLastError());
-    return vi_jacobi_solve(c, bc, N, T0, scl, d_y, recc, rcond, Cc, rankc, log, JACOBI_MAX_SWEEPS, nullptr, lam, 1, nrd,
-                           JACOBI_FLOOR_COLD);
+    int rc;
+    if (qr && (rc = vi_qr_precond(c, bc, N, T0, d_y, recc, T0, y1, hh, scr, (int64_t)(recb / 8))) != VI_OK) return rc;
+    rc = vi_jacobi_solve(c, bc, N, T0, scl, qr ? y1 : d_y, qr ? nullptr : recc, rcond, Cc, rankc, log, JACOBI_MAX_SWEEPS, nullptr,
+                         lam, 1, nrd, JACOBI_FLOOR_COLD, (int64_t)(recb / 16));
+    if (rc != VI_OK) return rc;
+    if (qr) return vi_qr_back_vec(c, bc, N, hh, Cc, (int64_t)(recb / 8));
+    return VI_OK;
 }
 
 // phase 2: eigenvectors from the logs, D1 = V^T (AWA V), D2 = V^T (R V) - four batched products in groups of fixed size
@@ -787,8 +855,13 @@ int prep_finish(vi_ctx* c, int64_t bc, int N, const void* log, const int* nrd, c
     const double** pR = pT1 + Bcp;
     const double** pD1 = pR + Bcp;
     const double** pD2 = pD1 + Bcp;
-    int rc = vi_jacobi_vectors(c, bc, N, log, JACOBI_MAX_SWEEPS, nrd, Vc);
+    const size_t recb = log_record_bytes(N);
+    int rc = vi_jacobi_vectors(c, bc, N, log, JACOBI_MAX_SWEEPS, nrd, Vc, (int64_t)(recb / 16));
     if (rc != VI_OK) return rc;
+    if (qr_enabled(N)) {          // eigenvectors of X1 = Q^T X Q -> eigenvectors of X
+        const double* hh = (const double*)((const char*)log + vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS));
+        if ((rc = vi_qr_back_mat(c, bc, N, hh, Vc, (int64_t)(recb / 8))) != VI_OK) return rc;
+    }
     hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, T0);
     VI_HIP(hipGetLastError());
     if ((rc = group_ptrs(c, bc, T0, NN, nullptr, 0, pT0)) != VI_OK) return rc;
@@ -822,8 +895,8 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     }
     VI_HIP(hipSetDevice(c->device));
     const int NN = N * N;
-    const size_t logb = vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS);
-    const size_t per = logb + (size_t)(N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * NN * sizeof(double) + 6 * sizeof(void*);
+    const size_t logb = log_record_bytes(N);
+    const size_t per = logb + (size_t)(2 * N + 1) * sizeof(double) + sizeof(int) + (size_t)2 * NN * sizeof(double) + 6 * sizeof(void*);
     // chunks of records, so that the rotation logs and temporaries stay within 4 GiB of workspace (4.3 MB per record at
     // N = 144: 10 000 records at once would ask for 43 GB)
     int64_t Bc = (int64_t)(((size_t)4 << 30) / per);
@@ -842,11 +915,12 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
     double* scrT = T1 + (size_t)Bc * NN;   // results of the padding entries of the last product group
     double* scrD = scrT + (size_t)GEMM_GROUP * NN;
     const double** parr = (const double**)(scrD + (size_t)GEMM_GROUP * NN);
-    int* nrd = (int*)(parr + 6 * Bcp);
+    double* y1 = (double*)(parr + 6 * Bcp);
+    int* nrd = (int*)(y1 + (size_t)Bc * N);
     for (int64_t i0 = 0; i0 < B; i0 += Bc) {
         const int64_t bc = (B - i0) < Bc ? (B - i0) : Bc;
         rc = prep_decompose(c, bc, N, d_AWA, d_rec + i0, d_alpha0 + i0, d_R, d_y, rcond, d_C + i0 * N,
-                            d_rank ? d_rank + i0 : nullptr, ws, scl, lam, T0, nrd);
+                            d_rank ? d_rank + i0 : nullptr, ws, scl, lam, T0, nrd, y1, T1);
         if (rc != VI_OK) return rc;
         rc = prep_finish(c, bc, N, ws, nrd, d_AWA, d_rec + i0, d_R, d_y, d_V + i0 * NN, d_D1 + i0 * NN, d_D2 + i0 * NN,
                          d_yt + i0 * N, T0, T1, scrT, scrD, parr, Bcp);
@@ -859,7 +933,7 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
 // (vi_rotation_log_bytes(N) per system): a record fitted alone decomposes the systems at the middle of ALL its candidate
 // brackets in the launch of its bracket walk (room for 256 systems, as long as the slowest one) and finishes - eigenvectors
 // and the three products - only the one the walk then points at.
-extern "C" size_t vi_rotation_log_bytes(int32_t N) { return vi_jacobi_log_bytes(N, JACOBI_MAX_SWEEPS); }
+extern "C" size_t vi_rotation_log_bytes(int32_t N) { return log_record_bytes(N); }
 
 extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                                 const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,
@@ -875,12 +949,14 @@ extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d
     VI_HIP(hipSetDevice(c->device));
     const int NN = N * N;
     void* ws = nullptr;
-    int rc = vi_ctx_workspace(c, (size_t)B * ((size_t)(N + 1 + NN) * sizeof(double)) + 1024, &ws);
+    int rc = vi_ctx_workspace(c, (size_t)B * ((size_t)(2 * N + 1 + 2 * NN) * sizeof(double)) + 1024, &ws);
     if (rc != VI_OK) return rc;
     double* scl = (double*)ws;
     double* lam = scl + B;
     double* T0 = lam + (size_t)B * N;
-    return prep_decompose(c, B, N, d_AWA, d_rec, d_alpha0, d_R, d_y, rcond, d_C, d_rank, d_log, scl, lam, T0, d_nround);
+    double* scr = T0 + (size_t)B * NN;
+    double* y1 = scr + (size_t)B * NN;
+    return prep_decompose(c, B, N, d_AWA, d_rec, d_alpha0, d_R, d_y, rcond, d_C, d_rank, d_log, scl, lam, T0, d_nround, y1, scr);
 }
 
 extern "C" int vi_warm_finish_f64(vi_ctx* c, int64_t B, int32_t N, const void* d_log, const int32_t* d_nround,

@@ -682,12 +682,12 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps) { return (size_t)jacobi_log_st
 template <int IT>
 static int launch_jacobi(vi_ctx* c, int threads, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                          const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor)
+                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride_in)
 {
     const size_t shm = vi_jacobi_lds_bytes(N);
     // per launch, not cached: a context per device may exist in one process and the attribute is per device
     VI_HIP(hipFuncSetAttribute((const void*)k_jacobi_solve<IT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    const int64_t log_stride = jacobi_log_stride(N, max_sweeps);
+    const int64_t log_stride = log_stride_in > 0 ? log_stride_in : jacobi_log_stride(N, max_sweeps);
     // abs_floor: the systems are scaled to max|X| in [1, 2).  Cold solves pass 1e-22: off-diagonal elements
     // below it cannot move any kept eigenvalue (|lambda| > eps * max|lambda|) by more than 1e-6 of itself.
     // Warm solves pass 1e-16: the rotated system D1 + alpha D2 carries formation errors of N*eps anyway.
@@ -705,14 +705,15 @@ static int launch_jacobi(vi_ctx* c, int threads, int64_t B, int N, const double*
     return VI_OK;
 }
 
-// d_X: systems scaled by k_scale_system (B x N x N, only read).
+// d_X: systems scaled by k_scale_system (B x N x N, only read).  log_stride (in 16-byte rotation entries, 0 = the logs
+// lie back to back): distance between the rotation logs of consecutive systems in d_log.
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor)
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride)
 {
     int threads, it;
     jacobi_geometry(N, threads, it);
-#define VI_J(IT) return launch_jacobi<IT>(c, threads, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor)
+#define VI_J(IT) return launch_jacobi<IT>(c, threads, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor, log_stride)
     if (it <= 1) VI_J(1);
     if (it <= 2) VI_J(2);
     VI_J(3);
@@ -722,13 +723,14 @@ int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double
 // Eigenvectors (column k = eigenvector of slot k, LAPACK layout) from the rotation logs of vi_jacobi_solve.
 bool vi_jacobi_vectors_supported(int N) { return vi_jacobi_supported(N); }
 
-int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V)
+int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V,
+                      int64_t log_stride_in)
 {
     // one wave per column strip with the columns in registers; very few systems (one record's prepare / final solve):
     // one column per wave, spread over as many CUs as there are columns (latency); many systems: eight columns per wave,
     // so that a system's rotation log is read N / 8 times (throughput).  The strips of one system are neighbours in the
     // grid (x fastest), so they read its log together through L2.
-    const int64_t log_stride = jacobi_log_stride(N, max_sweeps);
+    const int64_t log_stride = log_stride_in > 0 ? log_stride_in : jacobi_log_stride(N, max_sweeps);
     // columns per wave: as few as keeps ~8 waves per CU busy (a wave with 8 columns takes 8 times as long as one with 1;
     // the handful of systems of a re-basing round waited 1.2-2.9 ms for 18 waves per system while the chip stood empty).
     // All instances do the same arithmetic per column (WaveReplay::inv), so the choice does not show in the result.
