@@ -97,6 +97,8 @@ int  vi_d2h(vi_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* syn
 int  vi_dmemset(vi_ctx* ctx, void* d_ptr, int value, size_t bytes);
 
 /* HIP-event timing on the context's stream (bench.py measures kernels on the stream they run on) */
+/* free / total memory of the context's device (hipMemGetInfo) */
+int  vi_mem_info(vi_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int  vi_timer_start(vi_ctx* ctx);
 int  vi_timer_stop_ms(vi_ctx* ctx, double* ms);   /* synchronises on the stop event */
 
@@ -203,7 +205,11 @@ int  vi_warm_prepare_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA,
                          double* d_C, int32_t* d_rank, double* d_V, double* d_D1, double* d_D2, double* d_yt);
 int  vi_warm_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_D1, const double* d_D2,
                        const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
-                       double rcond, double* d_C, int32_t* d_rank);
+                       double rcond, double* d_C, int32_t* d_rank, int32_t* d_sweeps /* may be NULL */);
+/* d_sweeps (here and in vi_basis_solve_f64 / vi_warm_rebase_f64): Jacobi sweeps each system took, or the sweep cap + 1
+ * (vi_max_sweeps() + 1) when the cap ended the iteration before it converged - such a solution must not decide a sign
+ * of chi^2 - nu (interpolate.py:193-203); the caller solves that system again from X(alpha) itself. */
+int  vi_max_sweeps(void);
 
 /* The two phases of vi_warm_prepare_f64 as separate calls: vi_decompose_f64 forms and decomposes X(alpha0[i]) of B records
  * (solution to d_C as vi_solve_trunc_f64 gives it) and leaves the rotation logs - vi_rotation_log_bytes(N) per system - and
@@ -225,7 +231,8 @@ int  vi_warm_finish_f64(vi_ctx* ctx, int64_t B, int32_t N, const void* d_log, co
  * nplain triples are plain warm solves (no re-basing) that share the eigen-solve launch of the others. */
 int  vi_warm_rebase_f64(vi_ctx* ctx, int64_t B, int64_t nplain, int32_t N, const double* d_AWA, const double* d_R,
                         const double* d_y, const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha, double rcond,
-                        double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank);
+                        double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C, int32_t* d_rank,
+                        int32_t* d_sweeps /* may be NULL */);
 
 /* out[t] = the alpha below which alpha R vanishes from AWA[t] + alpha R in floating point (alpha |R_ij| under a quarter
  * of eps |AWA_ij| in every element): the systems of the bracket walk (interpolate.py:186-203) below it are one and the
@@ -239,11 +246,12 @@ int  vi_reg_floor_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_AWA, co
  * vi_solve_trunc_f64, C = V c'.  1-4 Jacobi sweeps per system instead of 8-24. */
 int  vi_basis_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const double* d_y,
                         const int32_t* d_rec, const int32_t* d_basis, const double* d_alpha, const double* d_V,
-                        const double* d_D2, double rcond, double* d_C, int32_t* d_rank);
+                        const double* d_D2, double rcond, double* d_C, int32_t* d_rank, int32_t* d_sweeps /* may be NULL */);
 
 /* One root-finder iterate of ONE record in a single call (single-record latency path): vi_warm_solve_f64 for
  * (slot, alpha) followed by vi_chi2_f64 against record `rec`; the scalars travel as kernel arguments and the only
- * synchronisation is the read-back of chi^2 into *h_chi2 (host).  d_scratch: N + 8 doubles of device memory. */
+ * synchronisation is the read-back into h_chi2 (host, THREE doubles: chi^2, an internal word, and in the low 32 bits of
+ * the third the sweep count of the solve - cap + 1 when it did not converge).  d_scratch: N + 8 doubles of device memory. */
 int  vi_warm_chi2_one_f64(vi_ctx* ctx, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
                           const double* d_yt, const double* d_V, int32_t slot, double alpha, double rcond,
                           const double* d_At, int32_t rec, const double* d_W, const double* d_b,

@@ -127,6 +127,58 @@ def test_c1_fit_is_independent_of_the_batch_and_consistent(monkeypatch):
     assert nroot >= 30
 
 
+def test_repeated_fits_do_not_leak_pipeline_contexts(monkeypatch):
+    """A second fit() / upload_records() on the same engine re-uses its pipeline sub-engines (their contexts own a stream,
+    a rocBLAS handle, 2 x 2048 events and a grow-only workspace of up to gigabytes): free device memory after the second
+    and the sixth fit differs by less than one workspace, and the results are the same every time."""
+    from volumetricinterp_amd import synth
+    monkeypatch.setenv('VINTERP_PIPELINES', '2')
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 24
+    value, error = synth.synth_records(A, T, seed0=4000)
+    W = error**-2.
+    first = eng.fit(W, value, [P] * T)
+    subs = [id(s) for s in eng._subs]
+    eng.fit(W, value, [P] * T)
+    ctx.sync()
+    free2 = ctx.mem_info()[0]
+    for _ in range(4):
+        last = eng.fit(W, value, [P] * T)
+    ctx.sync()
+    free6 = ctx.mem_info()[0]
+    assert [id(s) for s in eng._subs] == subs                      # the same sub-engines, not fresh ones
+    assert abs(free6 - free2) <= 64 << 20, (free2, free6)           # (a leaked context + workspace is >= 1 GiB here)
+    assert np.array_equal(first['Coeffs'], last['Coeffs'], equal_nan=True)
+    eng.close()
+
+
+def test_record_with_most_points_dropped_inside_a_batch():
+    """A record whose points are mostly missing (W = 0: interpolate.py:516-520) lies far from the batch's mean system, in
+    whose eigenbases the bracket walk is solved; a rotated-system solve that the sweep cap ends before it converges is
+    reported by the library (sweeps = cap + 1) and solved again from X(alpha) itself.  Whatever happens on the way, the
+    record gets the answer it gets when fitted alone, bit for bit, and so do its neighbours."""
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 12
+    value, error = synth.synth_records(A, T, seed0=5000)
+    W = error**-2.
+    rng = np.random.default_rng(7)
+    keep = rng.random(P) < 0.12                    # record 5 keeps 12 % of its points
+    W[5, ~keep] = 0.
+    value[5, ~keep] = 0.
+    npts = [P] * T
+    npts[5] = int(keep.sum())
+    full = eng.fit(W, value, npts)
+    assert eng.stats.get('shared_solves', 0) > 0
+    print('unconverged rotated-system solves solved again cold:', eng.stats.get('unconverged_resolved', 0))
+    for t in (4, 5, 6):
+        one = eng.fit(W[t:t + 1], value[t:t + 1], npts[t:t + 1])
+        a1, a2 = one['reg_params'][0]['curvature'], full['reg_params'][t]['curvature']
+        assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (t, a1, a2)
+        assert np.array_equal(one['Coeffs'][0], full['Coeffs'][t], equal_nan=True), t
+    eng.close()
+
+
 def test_pipelines_change_nothing_but_the_time(monkeypatch):
     """fit_resident runs a batch as concurrent sub-batches, each on its own context and host thread (FitEngine.
     _fit_pipelined): 48 records as one, two and three pipelines give the same alpha, chi^2, coefficients, covariances and

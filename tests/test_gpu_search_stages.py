@@ -8,7 +8,7 @@ NumPy / LAPACK on the same inputs, at the benchmarked order (N = 144, 26 x 100 p
 import numpy as np
 import pytest
 
-from conftest import rel
+from conftest import load_golden, rel
 from test_gpu_configs import _engine, CFG144, EPS
 
 pytestmark = pytest.mark.gpu
@@ -84,7 +84,7 @@ def test_basis_solve_equals_cold_solve_in_any_basis(setup):
     dC, drk = ctx.empty((B, N)), ctx.empty((B,), np.int32)
     drec, dbas, dal = ctx.to_device(rec), ctx.to_device(bas), ctx.to_device(al)
     _lib.check(_lib.lib.vi_basis_solve_f64(h, B, N, dAWA.ptr, dy.ptr, drec.ptr, dbas.ptr, dal.ptr, dV.ptr, dD2.ptr, EPS, dC.ptr,
-                                           drk.ptr), 'basis_solve')
+                                           drk.ptr, None), 'basis_solve')
     Cs = dC.download()
     dX = ctx.to_device(np.stack([s['AWA'][r] + a * s['R'] for r, a in zip(rec, al)]))
     dCc, drc = ctx.empty((B, N)), ctx.empty((B,), np.int32)
@@ -105,7 +105,7 @@ def test_basis_solve_equals_cold_solve_in_any_basis(setup):
     dC1 = ctx.empty((1, N))
     da1, drk1 = ctx.to_device(np.array([1e-12])), ctx.empty((1,), np.int32)
     _lib.check(_lib.lib.vi_basis_solve_f64(h, 1, N, dAWA.ptr, dy.ptr, one.ptr, one.ptr, da1.ptr, dVr.ptr, dD2r.ptr, EPS, dC1.ptr,
-                                           drk1.ptr), 'basis_solve')
+                                           drk1.ptr, None), 'basis_solve')
     import scipy.linalg
     Cl = scipy.linalg.lstsq(s['AWA'][0] + 1e-12 * s['R'], s['y'][0])[0]
     assert abs(_chi2(s, dC1.download()[0], 0) / _chi2(s, Cl, 0) - 1.) <= 1e-6
@@ -163,19 +163,19 @@ def test_rebase_moves_the_rotated_system_and_keeps_the_solution(setup):
     slot = ctx.to_device(np.arange(B, dtype=np.int32))
     dal = ctx.to_device(10.**x1)
     dCw = ctx.empty((B, N))
-    _lib.check(_lib.lib.vi_warm_solve_f64(h, B, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot.ptr, dal.ptr, EPS, dCw.ptr, drk.ptr),
+    _lib.check(_lib.lib.vi_warm_solve_f64(h, B, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot.ptr, dal.ptr, EPS, dCw.ptr, drk.ptr, None),
                'warm')
     dCr = ctx.empty((B, N))
     # record 0 rides along as a plain warm solve (nplain = 1): its rotated system must stay where it is
     keep0 = [x.download()[0].copy() for x in (dV, dD1, dD2, dyt)]
     _lib.check(_lib.lib.vi_warm_rebase_f64(h, B, 1, N, eng.dAWA.ptr, eng.R['curvature'].ptr, eng.dy.ptr, drec.ptr, slot.ptr, dal.ptr,
-                                           EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr), 'rebase')
+                                           EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr, None), 'rebase')
     assert np.array_equal(dCr.download(), dCw.download())          # the solutions returned are the warm solve's
     for a, b in zip(keep0, (dV, dD1, dD2, dyt)):
         assert np.array_equal(a, b.download()[0])
     # now all three re-base (record 0 too)
     _lib.check(_lib.lib.vi_warm_rebase_f64(h, B, 0, N, eng.dAWA.ptr, eng.R['curvature'].ptr, eng.dy.ptr, drec.ptr, slot.ptr, dal.ptr,
-                                           EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr), 'rebase')
+                                           EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr, dCr.ptr, drk.ptr, None), 'rebase')
     V, D1, D2, yt = dV.download(), dD1.download(), dD2.download(), dyt.download()
     for i, t in enumerate(rec):
         Vm = V[i].T                                               # columns = basis vectors
@@ -189,7 +189,7 @@ def test_rebase_moves_the_rotated_system_and_keeps_the_solution(setup):
     # a warm solve 1e-4 decades away, from the new basis, against the cold solve there
     x2 = x1 + 1e-4
     dal2 = ctx.to_device(10.**x2)
-    _lib.check(_lib.lib.vi_warm_solve_f64(h, B, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot.ptr, dal2.ptr, EPS, dCw.ptr, drk.ptr),
+    _lib.check(_lib.lib.vi_warm_solve_f64(h, B, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot.ptr, dal2.ptr, EPS, dCw.ptr, drk.ptr, None),
                'warm')
     Cw = dCw.download()
     dX = ctx.to_device(np.stack([s['AWA'][t] + 10.**x * s['R'] for t, x in zip(rec, x2)]))
@@ -231,3 +231,41 @@ def test_chi2_kernel_has_one_summation_order(setup):
     ld = np.longdouble
     truth = float(np.sum((s['A'].astype(ld) @ C0.astype(ld) - s['b'][2].astype(ld))**2 * s['W'][2].astype(ld)))
     assert abs(vals[0] / truth - 1.) <= 1e-11
+
+
+def test_qr_similarity_preconditioner():
+    """vi_qr_similarity_f64 (csrc/vi_qr.hip): the pre-conditioner of the cold solves.  Q is orthogonal, X1 = Q^T X Q with
+    X the symmetric matrix made of the lower triangle (what the Jacobi kernel reads), y1 = Q^T y, to rounding - at the
+    benchmarked order on the reference's own systems and at small / odd orders (N = 27: the y column shares an octet with
+    the last matrix column; N = 36, 50: padded local rows)."""
+    from volumetricinterp_amd import _lib, fitengine  # noqa: F401
+    ctx = _lib.get_context()
+    e = load_golden('exact_default_c2')
+    rng = np.random.default_rng(3)
+    cases = [(e['X'], e['y'])]
+    for N in (27, 32, 36, 50, 96):
+        Xs = []
+        for _ in range(3):
+            Q, _r = np.linalg.qr(rng.standard_normal((N, N)))
+            lam = 10.0**rng.uniform(-30, 0, N) * rng.choice([-1, 1], N)
+            M = (Q * lam) @ Q.T
+            Xs.append(0.5 * (M + M.T))
+        cases.append((np.array(Xs), rng.standard_normal((3, N))))
+    z = np.zeros((2, 40, 40))
+    z[1, :10, :10] = cases[2][0][0][:10, :10]                     # all zero / rank 10: reflectors stop early
+    cases.append((z, rng.standard_normal((2, 40))))
+    for X, y in cases:
+        B, N = X.shape[0], X.shape[1]
+        Xs = np.array([x * 2.0**(1 - np.frexp(max(np.max(np.abs(x)), 1e-300))[1]) for x in X])
+        dX, dy = ctx.to_device(Xs), ctx.to_device(y)
+        dX1, dy1, dQ = ctx.empty((B, N, N)), ctx.empty((B, N)), ctx.empty((B, N, N))
+        _lib.check(_lib.lib.vi_qr_similarity_f64(ctx.handle, B, N, dX.ptr, dy.ptr, dX1.ptr, dy1.ptr, dQ.ptr), 'qr')
+        X1, y1, Q = dX1.download(), dy1.download(), dQ.download()
+        for i in range(B):
+            Qi = Q[i].T                                  # Q[:, j] contiguous
+            Xl = np.tril(Xs[i]) + np.tril(Xs[i], -1).T
+            sc = max(np.max(np.abs(Xl)), 1e-300)
+            assert np.max(np.abs(Qi.T @ Qi - np.eye(N))) <= 1e-13
+            assert np.max(np.abs(X1[i] - Qi.T @ Xl @ Qi)) <= 1e-13 * sc
+            assert np.max(np.abs(X1[i] - X1[i].T)) <= 1e-13 * sc
+            assert np.max(np.abs(y1[i] - Qi.T @ y[i])) <= 1e-13 * max(np.max(np.abs(y[i])), 1e-300)

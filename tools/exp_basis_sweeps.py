@@ -46,7 +46,7 @@ for k0 in (0, -8, -14, -18, -22, -25, -27, -29, -31, -34, -40):
     for i, k in enumerate(ks):
         da = ctx.to_device(np.array([10.0**k]))
         ctx.sync(); rounds()
-        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, rec.ptr, da.ptr, EPS, dC.ptr, drk.ptr), 'warm')
+        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, rec.ptr, da.ptr, EPS, dC.ptr, drk.ptr, None), 'warm')
         ctx.sync()
         sw.append(rounds() / ROUNDS); err.append(rel(dC.download()[0], Cc[i]))
     best = np.minimum(best, sw)

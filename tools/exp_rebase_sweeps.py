@@ -30,7 +30,7 @@ for j, x0 in ((0, -26.37), (1, -25.4), (3, -26.6)):
         da = ctx.to_device(np.array([10.0**(x0 + dx)]))
         ctx.sync(); ctx.solve_timing(1)
         ctx.timer_start()
-        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, rec.ptr, da.ptr, EPS, dC.ptr, drk.ptr), 'warm')
+        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, rec.ptr, da.ptr, EPS, dC.ptr, drk.ptr, None), 'warm')
         ms = ctx.timer_stop_ms()
         row.append('%g: %.1f sw %.2f ms' % (dx, ctx.solve_timing(1)['rounds'] / 72., ms))
     print('rec %d basis at %.2f | ' % (j, x0) + ' | '.join(row))

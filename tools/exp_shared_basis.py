@@ -57,7 +57,7 @@ for k in list(range(0, -50, -2)) + [-60, -80, -100]:
         sc = rounds(); c2c = chi2(dC.download()[0], j)
         dD1.upload((Vm.T @ AWA[j] @ Vm)[None]); dyt.upload((Vm.T @ y[j])[None])
         rounds()
-        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot0.ptr, al.ptr, EPS, dC.ptr, drk.ptr), 'warm')
+        _lib.check(_lib.lib.vi_warm_solve_f64(h, 1, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, slot0.ptr, al.ptr, EPS, dC.ptr, drk.ptr, None), 'warm')
         ss = rounds(); c2s = chi2(dC.download()[0], j)
         tot_c += sc; tot_s += ss
         row.append('       %4.0f  %5.0f   %9.1e ' % (sc, ss, abs(c2s - c2c) / c2c))

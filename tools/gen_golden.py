@@ -382,7 +382,17 @@ ROOTS_SEEDS = tuple(range(100, 116))
 
 def _roots_worker(job):
     """One perturbed reference run (all records of one geometry); returns plain arrays."""
-    tag, geom, T, seed0, perturb, workdir = job
+    tag, geom, T, seed0, perturb, workdir = job[:6]
+    driver = job[6] if len(job) > 6 else None
+    import scipy.linalg as _sl
+    if not hasattr(_sl, '_vi_orig_lstsq'):
+        _sl._vi_orig_lstsq = _sl.lstsq
+    if driver is None:
+        _sl.lstsq = _sl._vi_orig_lstsq
+    else:
+        # the reference calls scipy.linalg.lstsq(X, y, ...) with SciPy's default LAPACK driver (gelsd); this run uses
+        # another driver of the same SciPy function - same definition (minimum norm, rcond = eps), other rounding
+        _sl.lstsq = (lambda d: (lambda a, b, **kw: _sl._vi_orig_lstsq(a, b, lapack_driver=d, **kw)))(driver)
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
@@ -427,7 +437,7 @@ def _roots_worker(job):
             walk[tt, int(-a_)] = v_ + nu_
         else:
             nbrent[tt] += 1
-    return dict(tag=tag, perturb=perturb, alpha=alphas, Coeffs=it.Coeffs, chi_sq=it.chi_sq, dens=np.array(dens),
+    return dict(tag=tag, perturb=perturb, driver=driver, alpha=alphas, Coeffs=it.Coeffs, chi_sq=it.chi_sq, dens=np.array(dens),
                 nu=np.array(nu_last), walk=walk, nbrent=nbrent)
 
 
@@ -456,6 +466,41 @@ def gen_default_roots(workdir):
         for k in ('alpha', 'Coeffs', 'chi_sq', 'dens', 'nu', 'walk', 'nbrent'):
             out[tag + '_' + k] = np.array([r[k] for r in rs])
     save('fit_default_roots', **out)
+
+
+DRIVER_SEEDS = (None, 200, 201, 202, 203, 204, 205, 206)
+
+
+def gen_default_drivers(workdir):
+    """How much of the reference's answer at the default order is its LAPACK routine?  scipy.linalg.lstsq offers three
+    drivers for the same definition (minimum-norm solution, singular values below eps * sigma_max dropped): gelsd
+    (divide and conquer; SciPy's default, what the reference runs), gelss (QR-iteration SVD) and gelsy (complete
+    orthogonal factorisation).  Here the REFERENCE ITSELF is run with scipy.linalg.lstsq switched to gelss / gelsy (nothing
+    else changed), once as is and seven times with 1e-14 relative noise on its basis, on the records of fit_default_c2 and
+    fit_default16.  Together with fit_default_roots.npz (16 gelsd runs) this is the root set the GPU parity test measures
+    against: the reference's own spread under a perturbation of its input AND under an exchange of the library routine
+    that its source does not choose."""
+    import multiprocessing as mp
+    jobs = []
+    for drv in ('gelss', 'gelsy'):
+        for tag, geom, T, seed0 in [('default_c2', synth.GEOM_C2, 4, 1000), ('default16', synth.GEOM_C1, 16, 6000)]:
+            for s in DRIVER_SEEDS:
+                jobs.append((tag, geom, T, seed0, s, workdir, drv))
+    nproc = int(os.environ.get('VI_GOLD_PROCS', '7'))
+    with mp.get_context('fork').Pool(nproc, maxtasksperchild=1) as pool:
+        res = []
+        for r in pool.imap_unordered(_roots_worker, jobs):
+            res.append(r)
+            print(r['tag'], r['driver'], 'seed', r['perturb'], 'log10 alpha',
+                  np.round(np.log10(np.where(r['alpha'] > 0, r['alpha'], np.nan)), 4), flush=True)
+    out = dict(seeds=np.array([-1 if s is None else s for s in DRIVER_SEEDS]))
+    for drv in ('gelss', 'gelsy'):
+        for tag in ('default_c2', 'default16'):
+            rs = sorted([r for r in res if r['tag'] == tag and r['driver'] == drv],
+                        key=lambda r: -1 if r['perturb'] is None else r['perturb'])
+            for k in ('alpha', 'Coeffs', 'chi_sq', 'dens', 'nu', 'nbrent'):
+                out['%s_%s_%s' % (tag, drv, k)] = np.array([r[k] for r in rs])
+    save('fit_default_drivers', **out)
 
 
 def gen_grad(workdir):
@@ -561,7 +606,8 @@ def main():
     setup_reference(args.ref)
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
     steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval),
-             ('default_many', gen_default_many), ('default_roots', gen_default_roots)]
+             ('default_many', gen_default_many), ('default_roots', gen_default_roots),
+             ('default_drivers', gen_default_drivers)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue

@@ -26,8 +26,13 @@ if not os.path.exists(LIB_PATH):
 # The pipelines of a batched fit (fitengine.FitEngine._fit_pipelined) drive one GPU from up to four streams besides the
 # context's own; the runtime multiplexes streams onto 4 hardware queues by default and a fifth stream then waits behind an
 # unrelated one (measured: 1000 records in four pipelines 760 ms with 4 queues, 583 ms with 8).  Read by the HIP runtime when
-# it initialises, i.e. at the first library call below; an explicit setting in the environment wins.
+# it initialises, i.e. at the first library call below; an explicit setting in the environment wins.  It is a process-wide
+# setting that child processes inherit, and it has no effect when the HIP runtime was initialised before this module was
+# imported (another HIP library in the process): HW_QUEUES_REQUESTED records what this import found / asked for and
+# FitEngine.pipelines() falls back to two pipelines when the eight queues were not ours to ask for (README).
+HW_QUEUES_PRESET = os.environ.get('GPU_MAX_HW_QUEUES')
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+HW_QUEUES_REQUESTED = os.environ['GPU_MAX_HW_QUEUES']
 
 lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 
@@ -71,6 +76,7 @@ _sig('vi_dfree', C.c_int, VOIDP, VOIDP)
 _sig('vi_h2d', C.c_int, VOIDP, VOIDP, VOIDP, C.c_size_t)
 _sig('vi_d2h', C.c_int, VOIDP, VOIDP, VOIDP, C.c_size_t)
 _sig('vi_dmemset', C.c_int, VOIDP, VOIDP, C.c_int, C.c_size_t)
+_sig('vi_mem_info', C.c_int, VOIDP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig('vi_timer_start', C.c_int, VOIDP)
 _sig('vi_timer_stop_ms', C.c_int, VOIDP, c_double_p)
 _sig('vi_model_create', C.c_int, VOIDP, C.POINTER(ModelDesc), C.POINTER(VOIDP))
@@ -97,7 +103,7 @@ _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
 EXPORTS = ['vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
-           'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_timer_start', 'vi_timer_stop_ms',
+           'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_mem_info', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']
 
@@ -126,6 +132,12 @@ class Context:
 
     def sync(self):
         check(lib.vi_ctx_sync(self.handle), 'vi_ctx_sync')
+
+    def mem_info(self):
+        """(free, total) bytes of the device."""
+        fr, tot = C.c_size_t(0), C.c_size_t(0)
+        check(lib.vi_mem_info(self.handle, C.byref(fr), C.byref(tot)), 'vi_mem_info')
+        return fr.value, tot.value
 
     def timer_start(self):
         check(lib.vi_timer_start(self.handle), 'vi_timer_start')
@@ -163,6 +175,12 @@ class Context:
         if self.handle:
             lib.vi_ctx_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:                      # a context owns a stream, a rocBLAS handle, events and a grow-only device workspace
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceArray:

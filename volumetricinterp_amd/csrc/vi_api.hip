@@ -275,8 +275,10 @@ extern "C" void vi_model_destroy(vi_model* m)
     if (m->h_dhull) (void)hipFree(m->h_dhull);
     if (m->h_dout) (void)hipFree(m->h_dout);
     if (m->h_stream2) (void)hipStreamDestroy(m->h_stream2);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (m->h_ev[i]) (void)hipEventDestroy(m->h_ev[i]);
+        if (m->h_evdown[i]) (void)hipEventDestroy(m->h_evdown[i]);
+    }
     delete m;
 }
 
@@ -390,7 +392,7 @@ extern "C" int vi_eval_f64_host(vi_model* m, int64_t Q, const double* h_lat, con
     if (chunk > Q) chunk = Q;
     const int64_t nchunk = (Q + chunk - 1) / chunk;
     VI_HIP(hipStreamSynchronize(c->stream));          // nothing of an earlier call may still use the staging buffers
-    int rc;
+    int rc = VI_OK;
     if ((rc = grow(&m->h_din, &m->h_din_bytes, (size_t)2 * 3 * chunk * sizeof(double))) != VI_OK) return rc;
     if ((rc = grow(&m->h_dC, &m->h_dC_bytes, (size_t)T * m->N * sizeof(double))) != VI_OK) return rc;
     if ((rc = grow(&m->h_dout, &m->h_dout_bytes, (size_t)2 * T * chunk * sizeof(double))) != VI_OK) return rc;
@@ -398,39 +400,61 @@ extern "C" int vi_eval_f64_host(vi_model* m, int64_t Q, const double* h_lat, con
     if (!m->h_stream2) {
         VI_HIP(hipStreamCreateWithFlags(&m->h_stream2, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) VI_HIP(hipEventCreateWithFlags(&m->h_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) VI_HIP(hipEventCreateWithFlags(&m->h_evdown[i], hipEventDisableTiming));
     }
-    VI_HIP(hipMemcpyAsync(m->h_dC, h_C, (size_t)T * m->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (F > 0)
-        VI_HIP(hipMemcpyAsync(m->h_dhull, h_hull_eq, (size_t)F * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hipEvent_t down[2] = {nullptr, nullptr};          // "the download out of slot s has finished" (stream2)
-    hipEvent_t evdown[2];
-    for (int i = 0; i < 2; ++i) VI_HIP(hipEventCreateWithFlags(&evdown[i], hipEventDisableTiming));
-    rc = VI_OK;
-    for (int64_t k = 0; k < nchunk && rc == VI_OK; ++k) {
-        const int s = (int)(k & 1);
-        const int64_t q0 = k * chunk;
-        const int64_t qc = (Q - q0) < chunk ? (Q - q0) : chunk;
-        double* din = m->h_din + (size_t)s * 3 * chunk;
-        double* dout = m->h_dout + (size_t)s * T * chunk;
-        // slot s was last used by chunk k - 2: its download must be over before the kernel of chunk k overwrites dout
-        if (down[s]) VI_HIP(hipStreamWaitEvent(c->stream, down[s], 0));
-        VI_HIP(hipMemcpyAsync(din, h_lat + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        VI_HIP(hipMemcpyAsync(din + chunk, h_lon + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        VI_HIP(hipMemcpyAsync(din + 2 * chunk, h_alt + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        rc = vi_eval_f64(m, qc, din, din + chunk, din + 2 * chunk, T, m->h_dC, F > 0 ? m->h_dhull : nullptr, F, hull_tol, dout);
-        if (rc != VI_OK) break;
-        VI_HIP(hipEventRecord(m->h_ev[s], c->stream));
-        VI_HIP(hipStreamWaitEvent(m->h_stream2, m->h_ev[s], 0));
-        // device rows have length qc (the kernel wrote out[t * qc + q]); host rows have length Q
-        VI_HIP(hipMemcpy2DAsync(h_out + q0, (size_t)Q * sizeof(double), dout, (size_t)qc * sizeof(double),
-                                (size_t)qc * sizeof(double), (size_t)T, hipMemcpyDeviceToHost, m->h_stream2));
-        VI_HIP(hipEventRecord(evdown[s], m->h_stream2));
-        down[s] = evdown[s];
+    // From here on every failure leaves through ONE exit that waits for both streams: copies into the caller's arrays and
+    // out of the staging buffers may be in flight, and control must not return to Python while they are.
+#define VI_TRY(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            vi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            rc = VI_ERR_HIP;                                                                  \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+    {
+        bool used[2] = {false, false};                // "a download out of slot s has been issued" (stream2, h_evdown[s])
+        rc = VI_OK;
+        VI_TRY(hipMemcpyAsync(m->h_dC, h_C, (size_t)T * m->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (F > 0)
+            VI_TRY(hipMemcpyAsync(m->h_dhull, h_hull_eq, (size_t)F * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        for (int64_t k = 0; k < nchunk; ++k) {
+            const int s = (int)(k & 1);
+            const int64_t q0 = k * chunk;
+            const int64_t qc = (Q - q0) < chunk ? (Q - q0) : chunk;
+            double* din = m->h_din + (size_t)s * 3 * chunk;
+            double* dout = m->h_dout + (size_t)s * T * chunk;
+            // slot s was last used by chunk k - 2: its download must be over before the kernel of chunk k overwrites dout
+            if (used[s]) VI_TRY(hipStreamWaitEvent(c->stream, m->h_evdown[s], 0));
+            VI_TRY(hipMemcpyAsync(din, h_lat + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            VI_TRY(hipMemcpyAsync(din + chunk, h_lon + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            VI_TRY(hipMemcpyAsync(din + 2 * chunk, h_alt + q0, (size_t)qc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            rc = vi_eval_f64(m, qc, din, din + chunk, din + 2 * chunk, T, m->h_dC, F > 0 ? m->h_dhull : nullptr, F, hull_tol, dout);
+            if (rc != VI_OK) goto done;
+            VI_TRY(hipEventRecord(m->h_ev[s], c->stream));
+            VI_TRY(hipStreamWaitEvent(m->h_stream2, m->h_ev[s], 0));
+            // device rows have length qc (the kernel wrote out[t * qc + q]); host rows have length Q
+            VI_TRY(hipMemcpy2DAsync(h_out + q0, (size_t)Q * sizeof(double), dout, (size_t)qc * sizeof(double),
+                                    (size_t)qc * sizeof(double), (size_t)T, hipMemcpyDeviceToHost, m->h_stream2));
+            VI_TRY(hipEventRecord(m->h_evdown[s], m->h_stream2));
+            used[s] = true;
+        }
     }
+done:
+#undef VI_TRY
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(m->h_stream2);
-    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(evdown[i]);
     return rc;
+}
+
+// Free / total device memory of the context's GPU (tests: repeated fits must not leak contexts or workspaces).
+extern "C" int vi_mem_info(vi_ctx* c, size_t* free_bytes, size_t* total_bytes)
+{
+    VI_REQUIRE(c && free_bytes && total_bytes, "null argument");
+    VI_HIP(hipSetDevice(c->device));
+    VI_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return VI_OK;
 }
 
 // Page-locked host memory for callers that want the two directions of vi_eval_f64_host to overlap completely.

@@ -109,4 +109,5 @@ struct vi_model {
     double* h_dout = nullptr;    size_t h_dout_bytes = 0;
     hipStream_t h_stream2 = nullptr;
     hipEvent_t h_ev[2] = {nullptr, nullptr};
+    hipEvent_t h_evdown[2] = {nullptr, nullptr};   // "the download out of staging slot s has finished" (h_stream2)
 };

@@ -934,6 +934,7 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
 // brackets in the launch of its bracket walk (room for 256 systems, as long as the slowest one) and finishes - eigenvectors
 // and the three products - only the one the walk then points at.
 extern "C" size_t vi_rotation_log_bytes(int32_t N) { return log_record_bytes(N); }
+extern "C" int vi_max_sweeps(void) { return JACOBI_MAX_SWEEPS; }
 
 extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                                 const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,
@@ -986,7 +987,7 @@ extern "C" int vi_warm_finish_f64(vi_ctx* c, int64_t B, int32_t N, const void* d
 
 extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_D1, const double* d_D2,
                                  const double* d_yt, const double* d_V, const int32_t* d_slot, const double* d_alpha,
-                                 double rcond, double* d_C, int32_t* d_rank)
+                                 double rcond, double* d_C, int32_t* d_rank, int32_t* d_sweeps)
 {
     VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_slot && d_alpha && d_C, "null argument");
     VI_REQUIRE(B >= 0 && N > 0, "bad size");
@@ -1014,7 +1015,7 @@ extern "C" int vi_warm_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* 
         form_pair_scaled(c, bc, NN, d_D1, d_D2, d_slot + i0, d_slot + i0, d_alpha + i0, X, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, d_slot + i0, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
-                             JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
+                             JACOBI_MAX_SWEEPS, d_sweeps ? d_sweeps + i0 : nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_slot + i0, cp, d_C + i0 * N);
@@ -1086,7 +1087,7 @@ __global__ void k_basis_ptrs(int64_t B, int NN, const double* AWA, const int* __
 // Any orthonormal V gives the same solution in exact arithmetic - a poor reference costs sweeps, not correctness.
 extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const double* d_y,
                                   const int32_t* d_rec, const int32_t* d_basis, const double* d_alpha, const double* d_V,
-                                  const double* d_D2, double rcond, double* d_C, int32_t* d_rank)
+                                  const double* d_D2, double rcond, double* d_C, int32_t* d_rank, int32_t* d_sweeps)
 {
     VI_REQUIRE(c && d_AWA && d_y && d_rec && d_basis && d_alpha && d_V && d_D2 && d_C, "null argument");
     VI_REQUIRE(B >= 0 && N > 0, "bad size");
@@ -1130,7 +1131,7 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         form_pair_scaled(c, bc, NN, D1, d_D2, nullptr, d_basis + i0, d_alpha + i0, D1, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, D1, scl, yt, nullptr, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
-                             JACOBI_MAX_SWEEPS, nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
+                             JACOBI_MAX_SWEEPS, d_sweeps ? d_sweeps + i0 : nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_basis + i0, cp, d_C + i0 * N);
@@ -1153,12 +1154,12 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
 extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t N, const double* d_AWA, const double* d_R,
                                   const double* d_y, const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha,
                                   double rcond, double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C,
-                                  int32_t* d_rank)
+                                  int32_t* d_rank, int32_t* d_sweeps)
 {
     VI_REQUIRE(c && d_AWA && d_R && d_y && d_rec && d_slot && d_alpha && d_V && d_D1 && d_D2 && d_yt && d_C, "null argument");
     VI_REQUIRE(B >= 0 && N > 0 && nplain >= 0 && nplain <= B, "bad size");
     if (B == 0) return VI_OK;
-    if (nplain == B) return vi_warm_solve_f64(c, B, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank);
+    if (nplain == B) return vi_warm_solve_f64(c, B, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank, d_sweeps);
     if (!vi_jacobi_vectors_supported(N)) {
         vi_set_error("vi_warm_rebase_f64: N=%d outside the in-LDS Jacobi range", N);
         return VI_ERR_UNSUPPORTED;
@@ -1172,10 +1173,11 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t 
     if (Bc < 1) Bc = 1;
     if (nplain > 0 && B > Bc) {
         // more than one workspace chunk: the plain solves on their own, then the re-basing ones
-        int rc0 = vi_warm_solve_f64(c, nplain, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank);
+        int rc0 = vi_warm_solve_f64(c, nplain, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, d_rank, d_sweeps);
         if (rc0 != VI_OK) return rc0;
         return vi_warm_rebase_f64(c, B - nplain, 0, N, d_AWA, d_R, d_y, d_rec + nplain, d_slot + nplain, d_alpha + nplain, rcond,
-                                  d_V, d_D1, d_D2, d_yt, d_C + nplain * N, d_rank ? d_rank + nplain : nullptr);
+                                  d_V, d_D1, d_D2, d_yt, d_C + nplain * N, d_rank ? d_rank + nplain : nullptr,
+                                  d_sweeps ? d_sweeps + nplain : nullptr);
     }
     if (Bc > B) Bc = B;
     const int64_t Bcp = group_pad(Bc);
@@ -1207,7 +1209,7 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t 
         form_pair_scaled(c, bc, NN, d_D1, d_D2, slotc, slotc, d_alpha + i0, X, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, X, scl, d_yt, slotc, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws, JACOBI_MAX_SWEEPS,
-                             nullptr, nullptr, 0, nrd, JACOBI_FLOOR_WARM);
+                             d_sweeps ? d_sweeps + i0 : nullptr, nullptr, 0, nrd, JACOBI_FLOOR_WARM);
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V, slotc, cp,
                            d_C + i0 * N);
@@ -1272,14 +1274,17 @@ extern "C" int vi_warm_chi2_one_f64(vi_ctx* c, int32_t N, int64_t P, const doubl
     double* d_chi = d_scratch + 1;
     int32_t* d_slot = reinterpret_cast<int32_t*>(d_scratch + 2);
     int32_t* d_rec = d_slot + 1;
+    int32_t* d_sw = reinterpret_cast<int32_t*>(d_scratch + 3);
     double* d_C = d_scratch + 8;
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, c->stream, d_scratch, alpha, (int)slot, (int)rec);
     VI_HIP(hipGetLastError());
-    int rc = vi_warm_solve_f64(c, 1, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, nullptr);
+    int rc = vi_warm_solve_f64(c, 1, N, d_D1, d_D2, d_yt, d_V, d_slot, d_alpha, rcond, d_C, nullptr, d_sw);
     if (rc != VI_OK) return rc;
     rc = vi_chi2_f64(c, 1, P, N, d_At, d_C, d_rec, d_W, d_b, d_chi);
     if (rc != VI_OK) return rc;
-    VI_HIP(hipMemcpyAsync(h_chi2, d_chi, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // chi^2, alpha's slot word and the sweep count travel back together: h_chi2[0] = chi^2, and the low 32 bits of the
+    // third double are the sweeps of the solve (cap + 1: it did not converge and the value must not be used)
+    VI_HIP(hipMemcpyAsync(h_chi2, d_chi, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     VI_HIP(hipStreamSynchronize(c->stream));
     return VI_OK;
 }

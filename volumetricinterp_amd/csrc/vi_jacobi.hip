@@ -368,6 +368,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
     const double eps2 = 2.220446049250313e-16 * 2.220446049250313e-16;
     const double conv2 = VI_CONV_FACTOR * VI_CONV_FACTOR * eps2;      // termination test, see below
     int sweep = 0, ycur = 0;
+    bool converged = false;               // false: the sweep cap ended the iteration
     int64_t nround = 0;
 #ifdef VI_STAMPS
     unsigned long long stamp_t = __builtin_readcyclecounter();
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
         // applies the rotation criterion to every pair of an unchanged matrix, so its outcome is known now: test all
         // pairs in place (each thread its own blocks) and stop if none would rotate.  The slot arrangement after a
         // whole sweep is the initial one.
-        if (!__syncthreads_or(rotated)) { ++sweep; break; }
+        if (!__syncthreads_or(rotated)) { ++sweep; converged = true; break; }
         {
             int viol = 0;
 #pragma unroll
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
                         viol |= would_rotate(A[dg + p * M + tid], A[dg + q * M + tid], A[dg + j10(p, q) * M + tid], drop,
                                              abs_floor, conv2);
             }
-            if (!__syncthreads_or(viol)) { ++sweep; break; }
+            if (!__syncthreads_or(viol)) { ++sweep; converged = true; break; }
         }
     }
     // ---- truncated solve in the eigenbasis (slot order = original order) ------------------------------
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
         double tot = 0.0;
         for (int w = 0; w < nw; ++w) tot += nd[w];
         if (rank) rank[sys] = (int)tot;
-        if (sweeps_out) sweeps_out[sys] = sweep;
+        if (sweeps_out) sweeps_out[sys] = converged ? sweep : max_sweeps + 1;      // cap + 1: not converged
         if (nround_out) nround_out[sys] = (int)nround;
         if (round_acc) atomicAdd(round_acc, (unsigned long long)nround);      // bench only (vi_solve_timing)
     }

@@ -44,9 +44,10 @@ _lib._sig('vi_cov_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _
 _lib._sig('vi_warm_prepare_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
-          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_basis_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
-          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP)
+          _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+_lib._sig('vi_max_sweeps', C.c_int)
 _lib._sig('vi_reg_floor_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_rotation_log_bytes', C.c_size_t, C.c_int32)
 _lib._sig('vi_decompose_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
@@ -54,7 +55,8 @@ _lib._sig('vi_decompose_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VO
 _lib._sig('vi_warm_finish_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_warm_rebase_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
-          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+          _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
+          _lib.VOIDP)
 _lib._sig('vi_warm_chi2_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.c_int32, C.c_double, C.c_double, _lib.VOIDP, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           C.POINTER(C.c_double))
@@ -63,7 +65,7 @@ _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_qr_similarity_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP)
-_lib.EXPORTS += ['vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -136,7 +138,8 @@ class FitEngine(object):
         if W.shape != b.shape or W.ndim != 2 or W.shape[1] != self.P:
             raise ValueError('W, b must both be (T, %d)' % self.P)
         self.T = T = W.shape[0]
-        self._subs = None
+        # the pipeline sub-engines (and their contexts: stream, rocBLAS handle, events, workspace) are kept: they adopt
+        # the new views in _fit_pipelined; if the number of pipelines changes, _fit_pipelined closes them first
         self.dW = self._buf('W', W.shape).upload(W) if T else None
         self.db = self._buf('b', b.shape).upload(b) if T else None
         K = self.pipelines()
@@ -161,7 +164,7 @@ class FitEngine(object):
     def adopt_records(self, dW, db, T, Wref, bref):
         """Use T records already resident on the device (views into another engine's buffers)."""
         self.T = int(T)
-        self._subs = None
+        self._close_subs()
         self.dW, self.db = dW, db
         self._bounds = [0, self.T]
         self._ref_host = [(Wref, bref)]
@@ -176,7 +179,14 @@ class FitEngine(object):
         k = os.environ.get('VINTERP_PIPELINES')
         if k is not None:
             return max(1, min(int(k), max(1, self.T)))
-        return int(max(1, min(4, self.T // self.PIPELINE_MIN_RECORDS)))
+        # four pipelines need more hardware queues than the runtime's default of four (_lib asks for eight at import;
+        # with fewer - an explicit GPU_MAX_HW_QUEUES in the environment - two pipelines are what was measured to pay)
+        try:
+            queues = int(_lib.HW_QUEUES_REQUESTED)
+        except ValueError:
+            queues = 4
+        self.stats['hw_queues_requested'] = queues
+        return int(max(1, min(4 if queues >= 8 else 2, self.T // self.PIPELINE_MIN_RECORDS)))
 
     def form_normal_equations(self):
         """A^T W A (T,N,N) and A^T W b (T,N) of the resident records - once per record, not per alpha."""
@@ -330,13 +340,13 @@ class FitEngine(object):
                                                 dD1.offset_ptr(slot0 * N * N), dD2.offset_ptr(slot0 * N * N),
                                                 dyt.offset_ptr(slot0 * N)), 'vi_warm_prepare_f64')
 
-    def _warm_solve(self, tag, slots, recs, dalpha_ptr, n, dC_out, drank_out):
+    def _warm_solve(self, tag, slots, recs, dalpha_ptr, n, dC_out, drank_out, dsweeps_out=None):
         N, h = self.N, self.ctx.handle
         dV, dD1, dD2, dyt = self._warm_buffers(tag)
         sl = np.array([slots[int(r)] for r in recs], dtype=np.int32)
         dslot = self._buf(tag + 'slot', (n,), np.int32).upload(sl)
         _lib.check(_lib.lib.vi_warm_solve_f64(h, n, N, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, dslot.ptr, dalpha_ptr, EPS,
-                                              dC_out, drank_out), 'vi_warm_solve_f64')
+                                              dC_out, drank_out, dsweeps_out), 'vi_warm_solve_f64')
 
     def chi2_batch_search(self, rec, log10a, name, exact=None):
         """chi^2 requests of the search of `name`; see _chi2_batch_search_raw.  The bracket-walk requests (integer
@@ -410,19 +420,23 @@ class FitEngine(object):
             # a single root-finder iterate of a record whose rotated system exists: one library call, no uploads
             dV, dD1, dD2, dyt = self._warm_buffers('w_')
             scratch = self._buf('w_one', (N + 8,))
-            chi = C.c_double(0.)
+            back = np.zeros(3)                  # chi^2, an internal word, the sweep count (low 32 bits)
             r = int(rec[0])
             _lib.check(_lib.lib.vi_warm_chi2_one_f64(self.ctx.handle, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr,
                                                      self._warm_slot[r], float(np.power(10., log10a[0])), EPS,
                                                      self.At.ptr, r, self.dW.ptr, self.db.ptr, scratch.ptr,
-                                                     C.byref(chi)), 'vi_warm_chi2_one_f64')
+                                                     back.ctypes.data_as(C.POINTER(C.c_double))), 'vi_warm_chi2_one_f64')
             self.stats['solves'] += 1
             self.stats['launches'] += 1
             self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + 1
+            if int(back[2:3].view(np.int32)[0]) > self.max_sweeps():
+                # the sweep cap ended the solve: its value decides nothing - the same system from X(alpha) itself
+                self.stats['unconverged_resolved'] = self.stats.get('unconverged_resolved', 0) + 1
+                return self._cold_chi2(rec, np.power(10., log10a), name)
             if trace:
                 print('[search round] B=1 warm (single call)  %.2f ms  log10a[0]=%.12f' %
                       ((time.perf_counter() - t_tr) * 1e3, log10a[0]))
-            return np.array([chi.value])
+            return np.array([back[0]])
         if not self.warm_enabled():
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
@@ -484,6 +498,7 @@ class FitEngine(object):
         h = self.ctx.handle
         dCall = self._buf('w_C', (B, N))
         drank = self._buf('w_rank', (B,), np.int32)
+        dsw = self._buf('w_sweeps', (B,), np.int32)
         rec_o, alpha_o = rec[order], alpha[order]
         drec = self._buf('w_rec', (B,), np.int32).upload(rec_o)
         dal = self._buf('w_alpha', (B,)).upload(alpha_o)
@@ -530,11 +545,12 @@ class FitEngine(object):
                 np.array([self._basis_slot[k] for k in decades.tolist()], dtype=np.int32))
             _lib.check(_lib.lib.vi_basis_solve_f64(h, nsh, N, self.dAWA.ptr, self.dy.ptr, drec.offset_ptr(o),
                                                    dbs.ptr, dal.offset_ptr(o), dV.ptr, dD2.ptr, EPS,
-                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_basis_solve_f64')
+                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o), dsw.offset_ptr(o)),
+                       'vi_basis_solve_f64')
             o += nsh
         if nw and not nrb:
             self._warm_solve('w_', self._warm_slot, rec_o[o:o + nw], dal.offset_ptr(o), nw, dCall.offset_ptr(o * N),
-                             drank.offset_ptr(o))
+                             drank.offset_ptr(o), dsw.offset_ptr(o))
         elif nrb:
             # the plain warm solves of the round ride in the launch of the re-basing ones (a launch lasts as long as its
             # slowest system, however few it holds)
@@ -544,13 +560,25 @@ class FitEngine(object):
             dslot = self._buf('w_rbslot', (n,), np.int32).upload(sl)
             _lib.check(_lib.lib.vi_warm_rebase_f64(h, n, nw, N, self.dAWA.ptr, self.R[name].ptr, self.dy.ptr, drec.offset_ptr(o),
                                                    dslot.ptr, dal.offset_ptr(o), EPS, dV.ptr, dD1.ptr, dD2.ptr, dyt.ptr,
-                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o)), 'vi_warm_rebase_f64')
+                                                   dCall.offset_ptr(o * N), drank.offset_ptr(o), dsw.offset_ptr(o)),
+                       'vi_warm_rebase_f64')
             self.stats['rebased'] = self.stats.get('rebased', 0) + nrb
         dchi = self._buf('w_chi2', (B,))
         _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dCall.ptr, drec.ptr, self.dW.ptr, self.db.ptr,
                                         dchi.ptr), 'vi_chi2_f64')
         tmp = np.empty(B)
         _lib.check(_lib.lib.vi_d2h(h, tmp.ctypes.data_as(_lib.VOIDP), dchi.ptr, tmp.nbytes), 'd2h')
+        if B > nc:
+            # solves in a rotated system (shared walk bases, warm iterates) that the sweep cap ended before they converged:
+            # their chi^2 must not decide a sign or steer Brent - the same systems again from X(alpha) itself.  How many
+            # sweeps a rotated system takes depends on how far the record lies from the basis it is solved in (a record
+            # with most of its points dropped sits far from the batch's mean system).
+            sw = np.empty(B - nc, dtype=np.int32)
+            _lib.check(_lib.lib.vi_d2h(h, sw.ctypes.data_as(_lib.VOIDP), dsw.offset_ptr(nc), sw.nbytes), 'd2h')
+            bad = nc + np.nonzero(sw > self.max_sweeps())[0]
+            if len(bad):
+                tmp[bad] = self._cold_chi2(rec_o[bad], alpha_o[bad], name)
+                self.stats['unconverged_resolved'] = self.stats.get('unconverged_resolved', 0) + len(bad)
         out = np.empty(B)
         out[order] = tmp
         if trace:
@@ -561,6 +589,18 @@ class FitEngine(object):
         self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + nw + nrb
         self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
+
+    def max_sweeps(self):
+        v = getattr(self, '_max_sweeps', None)
+        if v is None:
+            v = self._max_sweeps = int(_lib.lib.vi_max_sweeps())
+        return v
+
+    def _cold_chi2(self, rec, alpha, name):
+        """chi^2 of (record, alpha) pairs from cold solves of X(alpha) itself (other parameters zero)."""
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        al = {n: (np.asarray(alpha, dtype=np.float64) if n == name else np.zeros(len(rec))) for n in self.regularization_list}
+        return self.chi2_batch(rec, al)
 
     def _walk_with_speculative_bases(self, rec, log10a, alpha, name, trace):
         """The bracket walk of a record fitted ALONE, with the rotated systems of all its candidate brackets.

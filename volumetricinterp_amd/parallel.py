@@ -113,8 +113,17 @@ def _peer_uid(conn):
 class SocketGroup(object):
     """Star-shaped control plane of the ranks of one node: rank 0 serves a Unix-domain socket."""
 
-    def __init__(self, rank, world, timeout=120.):
+    def __init__(self, rank, world, timeout=120., data_timeout=None):
+        """timeout: rendezvous (accept / connect).  data_timeout: the longest a rank waits inside allgather / bcast for a
+        slower peer - e.g. for rank 0 to finish its own share of a fit before it serves the gather; default
+        VINTERP_COMM_TIMEOUT seconds if set, else 10 x timeout; 0 or 'none' = wait for ever."""
         self.rank, self.world = rank, world
+        if data_timeout is None:
+            env = os.environ.get('VINTERP_COMM_TIMEOUT', '')
+            data_timeout = (None if env.strip().lower() in ('0', 'none', 'inf') else float(env)) if env else 10 * timeout
+        elif not data_timeout:
+            data_timeout = None
+        self.data_timeout = data_timeout
         run = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
         port = os.environ.get('MASTER_PORT', '0')
         self.path = os.environ.get('VINTERP_RDV_PATH') or os.path.join(_private_socket_dir(),
@@ -136,8 +145,17 @@ class SocketGroup(object):
                 if _peer_uid(conn) != os.getuid():          # not one of our ranks
                     conn.close()
                     continue
-                conn.settimeout(10 * timeout)               # finite: a dead rank must not hang the others for ever
+                conn.settimeout(timeout)
                 (r,) = struct.unpack('<I', _recv_exact(conn, 4))
+                if not (1 <= r < world) or r in self.peers:
+                    conn.close()
+                    for c in self.peers.values():
+                        c.close()
+                    srv.close()
+                    raise RuntimeError('rendezvous at %s: a peer announced rank %d (%s) - two launches sharing one '
+                                       'rendezvous path, or a wrong RANK / WORLD_SIZE in the environment'
+                                       % (self.path, r, 'already taken' if r in self.peers else 'world size %d' % world))
+                conn.settimeout(self.data_timeout)          # finite by default: a dead rank must not hang the others for ever
                 self.peers[r] = conn
             srv.close()
             try:
@@ -159,7 +177,7 @@ class SocketGroup(object):
             if _peer_uid(s) != os.getuid():
                 s.close()
                 raise PermissionError('the process serving %s does not belong to uid %d' % (self.path, os.getuid()))
-            s.settimeout(10 * timeout)
+            s.settimeout(self.data_timeout)
             s.sendall(struct.pack('<I', rank))
             self.sock = s
 
