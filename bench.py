@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the fit + evaluate hot path on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input: fit ONE record
-(26 beams x 100 ranges, default order MAXK=4 MAXL=6 -> N=144, curvature regularisation, chi^2 search,
-covariance) and evaluate the fitted model on a 128^3 geodetic query grid with the convex-hull mask on
-(the reference's default check_hull=True) - BASELINE.json configs[1].
+Workload "c1" (default at N = 1; BASELINE.json configs[1], the configuration the metric is quoted on): a "step" is one
+pass of the hot path over one batch of synthetic input - fit ONE record (26 beams x 100 ranges, default order MAXK=4
+MAXL=6 -> N=144, curvature regularisation, chi^2 search, covariance) and evaluate the fitted model on a 128^3 geodetic
+query grid with the convex-hull mask on (the reference's default check_hull=True).  Step t fits record t mod 16 of
+sixteen distinct resident records: the number of root-finder iterations (12-60, decided by where chi^2(alpha) jumps)
+differs from record to record, so the line reports the mean over the records together with median / min / max and
+the verdicts of the engine's consistency guard.
+Workload "c3" (default at N > 1; BASELINE.json configs[3]): 10000 timesteps of that geometry sharded ceil(T/N) per rank -
+independent records, no data-path collective -, each rank fits its shard as one batch and evaluates it on a 256^3 grid
+with the matrix-core kernel; the evaluation is MEASURED on a tile of 64 of the rank's timesteps and SCALED to its shard
+(a full pass is 150 s per rank at N = 8 and 20 min at N = 1); strong scaling, value = timesteps/s.
 Inputs (beam geometry, weights/data, query grid, regularisation matrix, hull facets) are resident in HBM before the
-timed region; outputs stay on the device.  With --gpus N > 1 every rank runs the same per-GPU workload on
-its own records (independent timesteps: weak scaling, no data-path collective); shared parameters are
-broadcast once from rank 0 over RCCL before the timed region.
+timed region; outputs stay on the device.  Shared parameters are broadcast once from rank 0 over RCCL before the timed
+region; if RCCL was to be used and did not come up, the line says so and the exit status is 3.
 
 `python bench.py --gpus N` without a torchrun environment starts N child processes itself (one per device, before
 anything touches a GPU) and prints the line rank 0 produced.
@@ -50,14 +56,23 @@ EVAL_FLOPS_PER_POINT = 3.0e3   # SURVEY 8d E1 estimate at the default order
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None, help='default: 16 (workload c1), 2 (workload c3)')
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', choices=('c1', 'c3'), default=None,
+                    help="c1: BASELINE configs[1], one record + 128^3 grid per step and GPU (default at N = 1); "
+                         "c3: configs[3], 10000 timesteps sharded over the ranks, 256^3 grid (default at N > 1)")
+    ap.add_argument('--records', type=int, default=10000, help='timesteps of workload c3 (all ranks together)')
     ap.add_argument('--grid', type=int, default=128, help='query grid edge (128 -> 128^3 points)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval-many', action='store_true', help='skip the secondary many-timesteps evaluation figure')
     ap.add_argument('--no-batched', action='store_true', help='skip the secondary batched-records figure (configs[2])')
     ap.add_argument('--batched-records', type=int, default=1000, help='records of the configs[2] figure')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.workload is None:
+        args.workload = 'c1' if args.gpus <= 1 else 'c3'
+    if args.steps is None:
+        args.steps = 16 if args.workload == 'c1' else 2
+    return args
 
 
 # ---- --gpus N without a launcher: start the ranks ourselves ---------------------------------------------------
@@ -184,6 +199,10 @@ def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    sys.exit(run(args))
+
+
+def run(args):
     # The contract is ONE JSON line on stdout.  Libraries loaded below (RCCL prints a version banner on
     # communicator creation) write to file descriptor 1 directly, so keep a private handle on the real stdout
     # and point fd 1 at stderr for the rest of the run.
@@ -236,14 +255,26 @@ def main():
     dlat, dlon, dalt = ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(alt)
     At = model.basis_device(dlat, dlon, dalt, P, transposed=True)
     A = At.download().T
+    if args.workload == 'c3':
+        out = run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world)
+        if rank == 0:
+            real_stdout.write(json.dumps(out) + '\n')
+            real_stdout.flush()
+        return finish(comm, world)
     T = 1
-    # every rank fits the same synthetic record(s): weak scaling means identical per-GPU work, and the number of
-    # Brent iterations (12-40, decided by noise at the default order) differs from record to record
-    value, error = synth.synth_records(A, T, seed0=1000)
-    W, b = error**-2., value
+    # Sixteen distinct synthetic records, each resident in its own engine (one record per step: the single-record latency
+    # path); the engines share their scratch buffers.  Every rank fits the same records: weak scaling means identical
+    # per-GPU work.  The number of root-finder iterations differs from record to record (12-60: where chi^2(alpha) jumps
+    # Brent bisects down to its 2e-12), so one hand-picked record says little.
+    NREC = 16
+    value, error = synth.synth_records(A, NREC, seed0=1000)
     npts = [P] * T
-    eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
-    eng.upload_records(W, b)
+    engs = []
+    for r in range(NREC):
+        e_ = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'], scratch_of=engs[0] if engs else None)
+        e_.upload_records(error[r:r + 1]**-2., value[r:r + 1])
+        engs.append(e_)
+    eng = engs[0]
     g = synth.query_grid(args.grid)
     Q = g[0].size
     dq = [ctx.to_device(a.ravel()) for a in g]
@@ -251,16 +282,35 @@ def main():
     dC = ctx.empty((T, N))
     dout = ctx.empty((T, Q))
 
-    fit_ms, eval_ms = [], []
+    fit_ms, eval_ms, step_ms, verdicts, step_info = [], [], [], [], []
 
     def eval_grid(dCx, Tx, doutx, hull=True):
         _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, Tx, dCx.ptr,
                                         dhull.ptr if hull else None, F if hull else 0, hull_tol if hull else 0.,
                                         doutx.ptr), 'vi_eval_f64')
 
-    def step(record=False):
+    def verdict(res):
+        """What the engine's consistency guard said about the record."""
+        oc = res['search']['curvature']['outcomes'][0]
+        if oc != 'root':
+            return oc, None
+        i0 = res['search']['curvature']['info'][0]
+        if i0.get('consistent'):
+            v = 'consistent'
+        elif i0.get('jump'):
+            v = 'jump'
+        elif i0.get('redone_cold'):
+            v = 'redone_cold'
+        elif 0 in res['search']['curvature'].get('polished_cold', []):
+            v = 'polished_cold'
+        else:
+            v = 'band'                           # 1e-6 nu < |chi^2 - nu| <= 1e-4 nu: the noise of the similarity transform
+        return v, i0
+
+    def step(i, record=False):
+        e_ = engs[i % NREC]
         t0 = time.perf_counter()
-        res = eng.fit_resident(npts, calccov=True)
+        res = e_.fit_resident(npts, calccov=True)
         Cfit = res['Coeffs']
         if not np.all(np.isfinite(Cfit)):          # NaN row (no root): evaluate zeros, work is the same
             Cfit = np.nan_to_num(Cfit)
@@ -269,25 +319,36 @@ def main():
         ctx.timer_start()                          # HIP events on the library's own stream, around the whole call
         eval_grid(dC, T, dout, hull=True)          # hull mask on: the reference default (estimate.py:75)
         ems = ctx.timer_stop_ms()
+        t2 = time.perf_counter()
         if record:
             fit_ms.append((t1 - t0) * 1e3)
             eval_ms.append(ems)
+            step_ms.append((t2 - t0) * 1e3)
+            v, i0 = verdict(res)
+            verdicts.append(v)
+            step_info.append({'record': i % NREC, 'ms': (t2 - t0) * 1e3, 'verdict': v,
+                              'iterations': i0.get('iterations') if i0 else None,
+                              'chi2_minus_nu': i0.get('chi2_minus_nu') if i0 else None,
+                              'log10_alpha': (float(np.log10(res['reg_params'][0]['curvature']))
+                                              if v not in ('no_root', 'too_smooth', 'skipped') and
+                                              res['reg_params'][0]['curvature'] > 0 else None)})
         return res
 
     def barrier():
         ctx.sync()
         comm.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     ctx.solve_timing(1)            # one HIP event pair around every eigen-solve kernel launch of the timed steps
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(record=True)
+    for i in range(args.steps):
+        res = step(i, record=True)
     barrier()
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     st = ctx.solve_timing(0)
+    solves_per_step = sum(e_.stats['solves'] for e_ in engs) / max(1, args.steps + args.warmup)
 
     def kernel_ms(fn, reps=5):
         best = float('inf')
@@ -380,22 +441,25 @@ def main():
         except Exception:
             pass
         pts = args.steps * Q * T * world
-        info0 = res['search']['curvature']['info'][0] if res['search']['curvature']['info'] else {}
         out = {
             'metric': 'fit+eval query-points/sec', 'value': pts / elapsed, 'unit': 'points/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: per GPU 1 record, 26-beam x 100-range fit (N=144, curvature, chi2 '
-                                   'search, covariance) + %d^3 geodetic query grid with the hull mask, fp64' % args.grid,
-                       'points_per_step_per_gpu': Q * T, 'timesteps_per_step_per_gpu': T},
+            'config': {'workload': 'configs[1]: per GPU and step 1 record (step t fits record t mod %d of %d distinct resident '
+                                   'records), 26-beam x 100-range fit (N=144, curvature, chi2 search, covariance) + %d^3 '
+                                   'geodetic query grid with the hull mask, fp64' % (NREC, NREC, args.grid),
+                       'points_per_step_per_gpu': Q * T, 'timesteps_per_step_per_gpu': T, 'distinct_records': NREC},
             'timesteps_per_sec': args.steps * T * world / elapsed,
+            'step_ms': {'mean': float(np.mean(step_ms)), 'median': float(np.median(step_ms)), 'min': float(np.min(step_ms)),
+                        'max': float(np.max(step_ms)), 'note': 'rank 0, per step (host clock around fit + evaluation); '
+                                                               'ms_per_step is the mean over the timed steps'},
+            'guard_verdicts': {v: verdicts.count(v) for v in sorted(set(verdicts))},
+            'steps_detail': step_info,
             'breakdown_ms': {'fit': float(np.mean(fit_ms)), 'eval_call_hull_on': ev,
-                             'fit_solves_per_step': eng.stats['solves'] / max(1, args.steps + args.warmup),
-                             'fit_outcome': res['search']['curvature']['outcomes'],
-                             'root_finder': [i.get('finder') for i in res['search']['curvature']['info']],
-                             'brent_iterations': info0.get('iterations'),
-                             'consistent': info0.get('consistent'), 'redone_cold': info0.get('redone_cold', False)},
+                             'fit_solves_per_step': solves_per_step,
+                             'brent_iterations_mean': float(np.mean([d['iterations'] for d in step_info
+                                                                     if d['iterations'] is not None] or [float('nan')]))},
             'eval_points_per_sec_per_gpu': Q * T / (ev * 1e-3),
             'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
         }
@@ -437,7 +501,9 @@ def main():
             'valu': {'achieved': EVAL_FLOPS_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e12, 'peak': FP64_PEAK_TF,
                      'unit': 'TFLOP/s', 'frac': EVAL_FLOPS_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e12 / FP64_PEAK_TF,
                      'flops_model': '~3.0 kflop/point at the default order (SURVEY 8d E1)'},
-            'points_per_sec_hull_on': Q * T / (ev_kernel_hull * 1e-3), 'points_per_sec_hull_off': Q * T / (ev_kernel_nohull * 1e-3)}
+            'points_per_sec_hull_on': Q * T / (ev * 1e-3), 'points_per_sec_hull_off': Q * T / (ev_kernel_nohull * 1e-3),
+            'hull_note': 'hull on: the whole vi_eval_f64 call (mask pass k_hull_mask + evaluation kernel, HIP events around '
+                         'the call); hull off: the evaluation kernel alone'}
         if many is not None:
             out['eval_many_timesteps'] = many
         if batched is not None:
@@ -446,12 +512,113 @@ def main():
             out['cpu_baseline'] = cpu
         real_stdout.write(json.dumps(out) + '\n')
         real_stdout.flush()
+    return finish(comm, world)
+
+
+def finish(comm, world):
+    """Close the process group; exit status 3 when RCCL was to carry the broadcast and did not come up (the line above
+    then says comm.rccl_broadcast = false: the parameters travelled over the control socket instead)."""
     comm.close()
+    rc = 0
+    if world > 1 and comm.backend == 'rccl' and not comm.rccl_ready:
+        sys.stderr.write('bench.py: RCCL did not initialise on %d ranks (%s); the shared parameters went over the control '
+                         'socket.  VINTERP_DIST_BACKEND=socket runs without RCCL on purpose.\n' % (world, '; '.join(comm.notes)))
+        rc = 3
     if any('did not return' in n for n in comm.notes):
         # a communicator bootstrap that never returned leaves a thread inside RCCL: skip the interpreter's and the
         # runtime's finalisers, which could block on it, now that the result line is out
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(rc)
+    return rc
+
+
+def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
+    """Workload c3 (BASELINE configs[3]): T timesteps sharded ceil(T / world) per rank, fitted as one batch per rank (chi^2
+    search, covariance), evaluated on a 256^3 grid by the matrix-core kernel.  The fit of the whole shard is inside the
+    timed region; the evaluation is measured there on a tile of TILE of the rank's timesteps and scaled to the shard."""
+    from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    from volumetricinterp_amd.parallel import shard_bounds
+    N, P = model.nbasis, A.shape[0]
+    Ttot = int(args.records)
+    lo, hi = shard_bounds(Ttot, rank, world)
+    share = hi - lo
+    TILE = min(64, max(1, share))
+    value, error = synth.synth_records(A, share, seed0=1000 + lo) if share else (np.zeros((0, P)), np.ones((0, P)))
+    eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
+    eng.upload_records(error**-2., value)
+    n = 256
+    g = synth.query_grid(n)
+    Q = g[0].size
+    dq = [ctx.to_device(a.ravel()) for a in g]
+    dhull = ctx.to_device(hull_eq)
+    F = hull_eq.shape[0]
+    dC = ctx.empty((TILE, N))
+    dout = ctx.empty((TILE, Q))
+    fit_s, tile_ms, outcomes = [], [], None
+
+    def step(record=False):
+        nonlocal outcomes
+        t0 = time.perf_counter()
+        res = eng.fit_resident([P] * share, calccov=True) if share else None
+        t1 = time.perf_counter()
+        ems = 0.
+        if share:
+            dC.upload(np.nan_to_num(res['Coeffs'][:TILE]))
+            ctx.timer_start()
+            _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, TILE, dC.ptr, dhull.ptr, F, hull_tol,
+                                            dout.ptr), 'vi_eval_f64')
+            ems = ctx.timer_stop_ms()
+            outcomes = res['search']['curvature']['outcomes']
+        if record:
+            fit_s.append(t1 - t0)
+            tile_ms.append(ems)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    ctx.sync()
+    comm.barrier()
+    wall = comm.max_over_ranks(time.perf_counter() - t0)
+    # per rank: the time a step takes with the evaluation of the whole shard = fit (measured) + tile (measured) x share / TILE
+    mine = (float(np.mean(fit_s)) + float(np.mean(tile_ms)) * 1e-3 * (share / max(1, TILE))) if share else 0.
+    per_rank = [float(np.frombuffer(b_, dtype=np.float64)[0]) for b_ in comm.allgather_bytes(np.array([mine]).tobytes())]
+    fits = [float(np.frombuffer(b_, dtype=np.float64)[0])
+            for b_ in comm.allgather_bytes(np.array([float(np.mean(fit_s)) if fit_s else 0.]).tobytes())]
+    step_s = max(per_rank)
+    if rank != 0:
+        return None
+    return {
+        'metric': 'fit+eval timesteps/sec', 'value': Ttot / step_s, 'unit': 'timesteps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'configs[3]: %d timesteps (26-beam x 100-range records, N=144, curvature, chi2 search, '
+                               'covariance) sharded ceil(T/N) per rank, no data-path collective; each rank fits its shard as '
+                               'one batch and evaluates it on a 256^3 geodetic grid with the hull mask (matrix-core kernel), '
+                               'fp64' % Ttot,
+                   'timesteps': Ttot, 'timesteps_per_rank': -(-Ttot // world), 'grid_points': Q,
+                   'evaluation': 'MEASURED on a tile of %d timesteps per rank inside the timed region and SCALED to the '
+                                 'rank\'s shard (a full pass is ~150 s per rank at 8 GPUs); the fit of the whole shard is '
+                                 'measured in full' % TILE},
+        'ms_per_step_measured_wall': wall / args.steps * 1e3,
+        'points_per_sec': Ttot * Q / step_s,
+        'per_rank_step_s': per_rank, 'per_rank_fit_s': fits,
+        'rank0': {'fit_s': float(np.mean(fit_s)) if fit_s else None, 'eval_tile_ms': float(np.mean(tile_ms)) if tile_ms else None,
+                  'eval_point_timesteps_per_sec': (TILE * Q / (float(np.mean(tile_ms)) * 1e-3)) if tile_ms else None,
+                  'records_per_sec_fit': share / float(np.mean(fit_s)) if fit_s else None,
+                  'outcomes': {o_: outcomes.count(o_) for o_ in set(outcomes)} if outcomes else None,
+                  'pipelines': eng.stats.get('pipelines', 1)},
+        'roofline': {'kernel': 'k_eval_sph_mfma (evaluation tile; the fit side is the k_jacobi_solve line of workload c1)',
+                     'bound': 'mfma', 'achieved': (2. * N * TILE * Q / (float(np.mean(tile_ms)) * 1e-3) / 1e12) if tile_ms else None,
+                     'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',
+                     'frac': (2. * N * TILE * Q / (float(np.mean(tile_ms)) * 1e-3) / 1e12 / FP64_PEAK_TF) if tile_ms else None,
+                     'traffic': None},
+        'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
+    }
 
 
 if __name__ == '__main__':

@@ -83,7 +83,13 @@ class _View(object):
 
 
 class FitEngine(object):
-    def __init__(self, ctx, At_dev, P, N, reg_matrices, regularization_list):
+    # device buffers that hold a record set between calls; every other buffer is scratch of the fit in progress
+    RESIDENT_BUFFERS = ('W', 'b', 'Wref', 'bref', 'AWA', 'y')
+
+    def __init__(self, ctx, At_dev, P, N, reg_matrices, regularization_list, scratch_of=None):
+        """scratch_of: another engine of the same context whose scratch buffers this one uses (engines that hold
+        different record sets of one geometry and are never fitted at the same time - bench.py's sixteen records)."""
+        self._scratch_of = scratch_of
         self.ctx = ctx
         self.At = At_dev
         self.P, self.N = int(P), int(N)
@@ -121,6 +127,8 @@ class FitEngine(object):
         return cls(ctx, At, A.shape[0], A.shape[1], reg_matrices, regularization_list)
 
     def _buf(self, name, shape, dtype=np.float64):
+        if self._scratch_of is not None and name not in self.RESIDENT_BUFFERS:
+            return self._scratch_of._buf(name, shape, dtype)
         n = int(np.prod(shape, dtype=np.int64))
         cur = self._bufs.get(name)
         if cur is None or cur.size < n or cur.dtype != np.dtype(dtype):
@@ -653,7 +661,8 @@ class FitEngine(object):
         slot = len(self._warm_slot)
         self._warm_slot[r] = slot
         dV, dD1, dD2, dyt = self._warm_buffers('w_')
-        dlog, dnr = self._bufs['sp_log'], self._bufs['sp_nround']
+        owner = self._scratch_of if self._scratch_of is not None else self
+        dlog, dnr = owner._bufs['sp_log'], owner._bufs['sp_nround']
         dr = self._buf('sp_rec1', (1,), np.int32).upload(np.array([r], dtype=np.int32))
         _lib.check(_lib.lib.vi_warm_finish_f64(h, 1, N, dlog.offset_ptr(j * (logb // 8)), dnr.offset_ptr(j), self.dAWA.ptr,
                                                dr.ptr, self.R[self._spec_name].ptr, self.dy.ptr, dV.offset_ptr(slot * N * N),

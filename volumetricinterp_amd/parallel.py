@@ -355,6 +355,16 @@ class Comm(object):
             return float(t.item())
         return max(struct.unpack('<d', p)[0] for p in self.grp.allgather(struct.pack('<d', float(x))))
 
+    def allgather_bytes(self, payload):
+        """Every rank contributes a byte string; every rank gets the list in rank order (control plane, small data)."""
+        if self.world <= 1:
+            return [payload]
+        if self.backend == 'gloo':
+            out = [None] * self.world
+            self.dist.all_gather_object(out, bytes(payload))
+            return out
+        return self.grp.allgather(bytes(payload))
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
