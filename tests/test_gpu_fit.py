@@ -121,6 +121,37 @@ def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
         assert it.fit_stats['solves'] < int(f['evalC_calls'])
 
 
+def test_small_order_root_does_not_depend_on_the_batch(tmp_path):
+    """Below N = 100 up to four records are searched by the guarded multisection (63 samples per round whatever the number
+    of records), larger batches by Brent alone.  Records fitted alone, in pairs and in fours get the same answer bit for
+    bit; in a batch of eight (Brent) the same root to 1e-7 decades - both finders stop at that precision on a function
+    whose own reproducibility in the reference is 1e-8 here - and coefficients within the north-star tolerance."""
+    from volumetricinterp_amd import synth
+    f = load_golden('fit_k8l2')
+    regm, reg = reg_of(f)
+    it = make_interp(tmp_path, str(f['cfg']))
+    A = it.model.basis(f['lat'], f['lon'], f['alt'])
+    value, error = synth.synth_records(A, 8, seed0=7000)
+    fits = {n: it.fit_records(f['lat'], f['lon'], f['alt'], value[:n], error[:n], regm) for n in (1, 2, 4, 8)}
+    for n in (2, 4):
+        a1, a2 = fits[1]['reg_params'][0][reg], fits[n]['reg_params'][0][reg]
+        assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (n, a1, a2)
+        assert np.array_equal(fits[1]['Coeffs'][0], fits[n]['Coeffs'][0], equal_nan=True), n
+    for t in range(2):
+        a2, a4 = fits[2]['reg_params'][t][reg], fits[4]['reg_params'][t][reg]
+        assert a2 == a4 or (np.isnan(a2) and np.isnan(a4))
+    nroot = 0
+    for t in range(4):
+        a4, a8 = fits[4]['reg_params'][t][reg], fits[8]['reg_params'][t][reg]
+        if np.isnan(a4) or np.isnan(a8) or a4 == 0 or a8 == 0:
+            assert (np.isnan(a4) and np.isnan(a8)) or a4 == a8
+            continue
+        nroot += 1
+        assert abs(math.log10(a4) - math.log10(a8)) <= 1e-7, (t, a4, a8)
+        assert rel(fits[4]['Coeffs'][t], fits[8]['Coeffs'][t]) <= 1e-6, t
+    assert nroot >= 2
+
+
 class _PerturbedBasis(object):
     """Oracle model whose basis carries 1e-14 relative noise: the screen tools/gen_golden.py applies to the reference
     itself (a record whose fit moves under it is decided by rounding - truncation rank flips at the rcond threshold,

@@ -700,8 +700,12 @@ class FitEngine(object):
         # Not at the default order and beyond (N >= 100): there the guard refuses on most brackets and the attempt is pure
         # cost - one launch of 254 warm systems, 3.1 ms of a 28.6 ms single-record fit (bench.py, 25.5 ms without it; the
         # rotated system sits at the middle of the bracket either way now, so Brent's steps and the answer are the same).
+        # The number of samples per round does not depend on the number of records (it used to be 256 / T - 1, so a record's
+        # last digits depended on whether it was fitted alone or with one to three others): 63 samples, 64-fold shrinkage,
+        # four rounds to 1e-7.  Batches of five records or more go straight to Brent, whose root agrees with the
+        # multisection's to ~1e-7 decades (tests/test_gpu_fit.py::test_small_order_root_does_not_depend_on_the_batch).
         if mode == 'multisection' or (self.T <= 4 and self.warm_enabled() and self.N < 100):
-            return int(max(15, min(255, 256 // max(1, self.T) - 1)))
+            return 63
         return 0
 
     def search(self, npts, prefetch=None, multisection=None, only=None, cold=False):
