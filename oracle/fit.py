@@ -18,15 +18,17 @@ from .geodesy import geodetic2ecef
 SCALE_FACTORS = (0.6, 0.7, 0.8, 0.9, 1.0)      # interpolate.py:173
 
 
-def eval_C(A, b, W, reg_matrices, reg_params, regularization_list, calccov=False):
-    """interpolate.py:432-469."""
+def eval_C(A, b, W, reg_matrices, reg_params, regularization_list, calccov=False, lapack_driver=None):
+    """interpolate.py:432-469.  lapack_driver: None = SciPy's default (gelsd), what the reference runs; 'gelss' / 'gelsy' =
+    the other LAPACK routines scipy.linalg.lstsq offers for the same definition (tests measure how much of the reference's
+    answer is its library routine)."""
     AWA = np.einsum('ji,j,jk->ik', A, W, A)
     X = AWA.copy()
     y = np.einsum('ji,j,j->i', A, W, b)
     for reg in regularization_list:
         X = X + reg_params[reg] * reg_matrices[reg]
     # LAPACK gelsd, cond=None -> eps; check_finite=True raises ValueError on NaN/inf
-    C = np.squeeze(scipy.linalg.lstsq(X, y)[0])
+    C = np.squeeze(scipy.linalg.lstsq(X, y, lapack_driver=lapack_driver)[0])
     if calccov:
         H = scipy.linalg.pinv(X)
         dC = np.einsum('ij,jk,kl->il', H, AWA, H)

@@ -217,3 +217,21 @@ def test_optimised_cpu_variant_equals_the_faithful_one():
     assert abs(c2 - c2s[0]) <= 1e-12 * c2s[0]
     assert np.linalg.norm(dC - dCs[0]) <= 1e-10 * np.linalg.norm(dCs[0])
     assert n_fast[0] < n_slow[0] // 2
+
+
+def test_accurate_oracle_against_exact_arithmetic():
+    """oracle/accurate.py (the arbiter of the GPU parity tests at the default order) against 50-digit arithmetic
+    (tools/gen_exact.py -> exact_default_c2.npz) on the reference's own 26 x 100 systems: rank, chi^2 and A c."""
+    import oracle
+    from oracle import accurate
+    e, f = load_golden('exact_default_c2'), load_golden('fit_default_c2')
+    A = oracle.SphHarmLagOracle().basis(f['lat'], f['lon'], f['alt'])
+    for i in range(e['X'].shape[0]):
+        c, rank = accurate.lstsq_accurate(e['X'][i], e['y'][i])
+        t = int(e['record'][i])
+        b, W = f['value'][t], f['error'][t]**-2.
+        chi = float(np.sum((A @ c - b)**2 * W))
+        assert rank == e['rank'][i]
+        assert abs(chi - e['chi2'][i]) <= 1e-10 * e['chi2'][i]          # LAPACK: 4e-4 .. 5e-2 on the same systems
+        assert rel(A @ c, A @ e['C'][i]) <= 1e-10
+        assert rel(c, e['C'][i]) <= 1e-8
