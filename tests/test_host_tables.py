@@ -51,3 +51,27 @@ def test_default_groups():
     # nu = 4, 22, 40, 58.00000000000001, 76, 94 -> one recurrence (fractional parts within SNAP_TOL)
     assert len(tb['groups']) == 1 and tb['groups'][0]['nvmax'] == 94 and tb['groups'][0]['nterms'] == 0
     assert [int(j) for j in np.nonzero(tb['groups'][0]['pick'] >= 0)[0]] == [4, 22, 40, 58, 76, 94]
+
+
+def test_psi_by_gauss_quadrature_matches_the_reference():
+    """SURVEY 8f row N4, the part that is well defined: Psi (sphharmlag.py:215-239) from an exact Gauss-Laguerre z-integral,
+    a Gauss-Legendre theta-integral and the analytic phi-integral (regmat.eval_psi_gauss) against the reference's own Psi
+    (tests/golden/regmat.npz, scipy.integrate.quad with its default 1.49e-8 tolerances): 5e-10 of max|Psi| on three
+    orders, and converged in itself to 1e-13 (so the difference is QUADPACK's).  Omega is not attempted: its z-integral
+    diverges and the reference's values are QUADPACK artefacts."""
+    import io
+    from conftest import load_golden
+    from volumetricinterp_amd import regmat
+    from volumetricinterp_amd.models.sphharmlag import Model
+    ref = load_golden('regmat')
+    for tag, (k, l) in (('default', (4, 6)), ('k8l2', (8, 2)), ('k4l3', (4, 3))):
+        cfg = ('[DEFAULT]\n[MODEL]\nNAME = sphharmlag\nMAXK = %d\nMAXL = %d\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\n'
+               'LONCP = 262\n' % (k, l))
+        m = Model(io.StringIO(cfg))
+        P = regmat.eval_psi_gauss(m)
+        R = ref[tag + '_0thorder']
+        assert P.shape == R.shape and np.array_equal(P, P.T)
+        assert np.max(np.abs(P - R)) <= 5e-10 * np.max(np.abs(R)), tag
+        P2 = regmat.eval_psi_gauss(m, ntheta=1200)
+        assert np.max(np.abs(P - P2)) <= 1e-13 * np.max(np.abs(P))
+        assert np.array_equal(m.eval_reg_matricies['0thorder'](), P)        # what the plug-in hands to the fit

@@ -320,13 +320,23 @@ class FitEngine(object):
         if last is None:
             return False
         done = self._rebased.get(r, 0)
-        if done == 0:
-            return abs(x - last) < self.REBASE_WITHIN
-        # a second time for the records that are still iterating after REBASE_AGAIN_AFTER requests: they sit on a jump of
+        sched = self._rebase_schedule()
+        if done < len(sched):
+            return abs(x - last) < sched[done]
+        # once more for the records that are still iterating after REBASE_AGAIN_AFTER requests: they sit on a jump of
         # chi^2 (an eigenvalue of X(alpha) at the cut), Brent bisects down to 2e-12 in 40-60 steps there, and from a basis
         # 1e-3 decades away those solves take 13 sweeps each
-        return (done == 1 and self._nreq.get(r, 0) >= self.REBASE_AGAIN_AFTER and abs(x - last) < self.REBASE_AGAIN_WITHIN
-                and os.environ.get('VINTERP_REBASE2', '1') != '0')
+        return (done == len(sched) and self._nreq.get(r, 0) >= self.REBASE_AGAIN_AFTER
+                and abs(x - last) < self.REBASE_AGAIN_WITHIN and os.environ.get('VINTERP_REBASE2', '1') != '0')
+
+    def _rebase_schedule(self):
+        """Thresholds (decades between two consecutive requests of a record) at which its rotated system is moved to the
+        current request: the k-th move happens the first time two consecutive requests lie closer than schedule[k]."""
+        v = getattr(self, '_rebase_sched', None)
+        if v is None:
+            e = os.environ.get('VINTERP_REBASE_SCHEDULE')
+            v = self._rebase_sched = tuple(float(x) for x in e.split(',')) if e else (self.REBASE_WITHIN,)
+        return v
 
     def _warm_buffers(self, tag):
         T, N = self.T, self.N
@@ -676,10 +686,12 @@ class FitEngine(object):
         # 64 or more - one syevd at N = 1152 is ~900 small dependent kernels, and only a batch fills the GPU - so a
         # single N = 1152 record takes 481 ms with the whole walk in one launch against 1164 ms four values at a time
         # (measured; running several syevd calls from concurrent host threads instead made it slower, 1460 ms).
+        if os.environ.get('VINTERP_PREFETCH'):
+            return int(os.environ['VINTERP_PREFETCH'])
         if self._ref_rec is not None and self.shared_walk_enabled():
             # in the shared bases a walk system costs a tenth of a cold one: fewer, fuller rounds (measured: 100 records
             # 224 -> 214 ms, 300 records in four pipelines 327 -> 323 ms, 1000 records unchanged)
-            return int(max(8, min(102, 8192 // max(1, self.T))))
+            return int(max(8, min(102, 32768 // max(1, self.T))))          # (1000 records: 8 -> 32 decades per round, 472 -> 450 ms)
         return int(max(8, min(102, 2048 // max(1, self.T))))
 
     def default_multisection(self):
@@ -864,8 +876,12 @@ class FitEngine(object):
         Between the two tolerances lies the noise of the warm transform itself (1e-6 .. 2e-6 of nu at N = 144, where
         the fit is only reproducible to 1e-3 anyway); redoing those cold would triple the cost of a batch for
         nothing."""
+        stamp = self._stage_stamp
+        stamp(None)
         params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
+        stamp('search')
         Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov, out=out)
+        stamp('finalize')
         if len(self.regularization_list) != 1 or os.environ.get('VINTERP_GUARD', '1') == '0':
             return params, infos, Coeffs, Cov, chi, ranks
         name = self.regularization_list[0]
@@ -952,6 +968,7 @@ class FitEngine(object):
                         inf['info'][t]['jump'] = True
                 bad = [t for t in bad if t not in sol]
         inf['redone_cold'] = list(bad)
+        stamp('guard')
         if bad and self.warm_enabled():
             p2, i2 = self.search(npts, prefetch=prefetch, only=bad, cold=True)
             C2, V2, c2, r2 = self.finalize(p2, calccov=calccov, only=set(bad))
@@ -967,11 +984,24 @@ class FitEngine(object):
             violators()
         return params, infos, Coeffs, Cov, chi, ranks
 
+    def _stage_stamp(self, name):
+        """VINTERP_STAGE_TIMES=1: wall time per stage of a fit (device drained at the boundaries) into stats['ms_<stage>']."""
+        if os.environ.get('VINTERP_STAGE_TIMES') != '1':
+            return
+        import time
+        self.ctx.sync()
+        now = time.perf_counter()
+        if name is not None:
+            self.stats['ms_' + name] = self.stats.get('ms_' + name, 0.) + (now - self._stage_t0) * 1e3
+        self._stage_t0 = now
+
     def fit_resident(self, npts, calccov=True, prefetch=None, multisection=None, _out=None):
         """Fit the records made resident by upload_records()."""
         if len(self._bounds) > 2:
             return self._fit_pipelined(npts, calccov, prefetch, multisection)
+        self._stage_stamp(None)
         self.form_normal_equations()
+        self._stage_stamp('normal_equations')
         params, infos, Coeffs, Cov, chi, ranks = self._search_and_finalize(npts, calccov, prefetch, multisection, out=_out)
         return dict(Coeffs=Coeffs, Covariance=Cov, chi_sq=chi, reg_params=params, ranks=ranks, search=infos)
 

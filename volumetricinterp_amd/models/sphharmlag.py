@@ -224,5 +224,10 @@ class Model(DeviceModel):
         return eval_omega(self)
 
     def eval_psi(self):
-        from ..regmat import eval_psi
-        return eval_psi(self)
+        # Gauss quadrature (regmat.eval_psi_gauss: exact z-integral, analytic phi-integral) unless the QUADPACK restatement
+        # of the reference is asked for (VINTERP_REGMAT=quad: bit-identical to the reference's Psi, a thousand times slower)
+        import os
+        from ..regmat import eval_psi, eval_psi_gauss
+        if os.environ.get('VINTERP_REGMAT', 'gauss') == 'quad':
+            return eval_psi(self)
+        return eval_psi_gauss(self)
