@@ -257,6 +257,22 @@ int  vi_warm_chi2_one_f64(vi_ctx* ctx, int32_t N, int64_t P, const double* d_D1,
                           const double* d_At, int32_t rec, const double* d_W, const double* d_b,
                           double* d_scratch, double* h_chi2);
 
+/* The whole root-finder phase of the search (scipy.optimize.brentq at interpolate.py:214 on chi^2(10^x) - nu) for ntask
+ * records in ONE launch: a workgroup owns a record from its unit bracket [xa, xb] (values fa, fb) to its root, every
+ * function value computed in place in the rotated system of the record's slot (vi_warm_prepare_f64) by the code of
+ * vi_warm_solve_f64 + vi_chi2_f64, alpha = vi_exp10 (below).  Device arrays of length ntask in and out: root and other end
+ * of the final bracket (log10 alpha), iterations / function calls as brentq counts them, status 0 = converged, 2 = a solve
+ * was ended by the sweep cap (run that record's iteration on the host), 3 = more than 100 iterations.  Bit for bit the
+ * result of the host-driven iteration from the same rotated system. */
+int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
+                       const double* d_yt, const double* d_V, const double* d_At, const double* d_W, const double* d_b,
+                       const int32_t* d_rec, const int32_t* d_slot, const double* d_xa, const double* d_xb,
+                       const double* d_fa, const double* d_fb, const double* d_nu, double rcond, double* d_root,
+                       double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status);
+/* out[i] = 10^x[i] (host arrays) in plain IEEE operations - the routine the device-side iteration uses, so that host and
+ * device form alpha = 10^(log10 alpha) identically (interpolate.py:216, :246) */
+int  vi_exp10_f64(const double* x, double* out, int64_t n);
+
 /* ---- generalised cross validation: replaces the loop of Interpolate.gcvobjfunct (interpolate.py:332-351) ----
  * For ONE record (d_AWA N x N, d_y N, d_W / d_b P) and one alpha: res[i] = W_p (a_p . C_(-p) - b_p)^2 for the np
  * data points p = pidx[i], where C_(-p) is the regularised truncated solution of the fit that leaves point p

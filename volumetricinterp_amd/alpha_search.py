@@ -408,7 +408,7 @@ def chi2_search_gen(npts, multisection=0, refine=False, prefetch=1, defer_brent=
                                                      iterations=iters, finder=finder, other_end=other_end)
 
 
-def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False, vector_brent=True):
+def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False, vector_brent=True, brent_solver=None):
     """Drive one search coroutine per record against a batched chi^2 evaluator.
 
     npts_list[i]: number of finite data points of record i (``len(b)``, interpolate.py:175), or None to
@@ -416,11 +416,15 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
     refine (see chi2_search_gen) it is also called as chi2_batch(rec, log10_alpha, exact: bool array).
     vector_brent: Brent's iteration of all records on arrays (BrentBatch) instead of one coroutine step per record and
     round; same iterates, same answers.
+    brent_solver(records, brackets) -> list of (root, iterations, funcalls, other_end) or None per record: Brent's whole
+    iteration for many records at once somewhere else (FitEngine: one kernel launch, a workgroup per record).  It is
+    called once, when every record's walk has ended; a record it answers None for is iterated here.
     Returns (alpha list, outcome list, info list, number of chi^2 evaluations).
     """
     T = len(npts_list)
-    brent = BrentBatch(T) if vector_brent else None
+    brent = BrentBatch(T) if (vector_brent or brent_solver is not None) else None
     brackets = {}
+    deferred = {}
     nu_arr = np.zeros(T)
     gens, pending = {}, {}
     cache = [dict() for _ in range(T)]
@@ -431,7 +435,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
         if n is None:
             results[i] = ('skipped', float('nan'), {})
             continue
-        g = chi2_search_gen(n, multisection=multisection, refine=refine, prefetch=prefetch, defer_brent=vector_brent)
+        g = chi2_search_gen(n, multisection=multisection, refine=refine, prefetch=prefetch, defer_brent=brent is not None)
         gens[i] = g
         pending[i] = next(g)
 
@@ -452,6 +456,9 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
             if stop.value[0] == 'bracket':          # the walk is done: Brent's iteration goes on in the batch
                 b = brackets[i] = stop.value[2]
                 nu_arr[i] = b['nu']
+                if brent_solver is not None and b['val'] != 0 and b['val0'] != 0:
+                    deferred[i] = b                 # iterated with all the others once the walks are over
+                    return
                 brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
                 if i in brent.results:
                     finish_brent(i)
@@ -488,7 +495,19 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
 
     for i in list(gens):
         serve(i)
-    while gens or (brent is not None and brent.active.any()):
+    while gens or deferred or (brent is not None and brent.active.any()):
+        if deferred and not gens:
+            ids = sorted(deferred)
+            for i, r_ in zip(ids, brent_solver(ids, [deferred[i] for i in ids])):
+                b = deferred.pop(i)
+                if r_ is None:
+                    brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
+                else:
+                    brent.results[i] = r_
+                    nevals += int(r_[2])
+                if i in brent.results:
+                    finish_brent(i)
+            continue
         rec, alp, exact = [], [], []
         bidx = None
         if brent is not None and brent.active.any():

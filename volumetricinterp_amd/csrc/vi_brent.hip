@@ -1,0 +1,299 @@
+// The root-finder phase of the regularisation-parameter search, one launch for a whole batch.
+//
+// Reference: scipy.optimize.brentq at volumetricinterp/interpolate.py:214 on f(x) = chi^2(10^x) - nu
+// (interpolate.py:220-261), x = log10(alpha) inside the unit bracket the walk found.  Brent's iteration is a chain of
+// dependent function values - 12-15 per record, 40-60 on the 15 % of the records whose bracket holds a jump of chi^2 -
+// and driven from the host (alpha_search.BrentBatch) every link of the chain is a round of launches for the whole batch:
+// form the rotated systems, solve, map back, chi^2, read back, NumPy.  A round lasts as long as its slowest system, the
+// last 50 rounds of a 1000-record batch carry a few dozen systems each, and the Python between the rounds is what four
+// concurrent pipelines end up waiting for.
+// Here a WORKGROUP owns a record from its bracket to its root: k_brent_warm takes records off a queue (atomic counter) and
+// runs brentq for each - the state machine in one lane, statement for statement alpha_search.brentq_gen with
+// multiply-add contraction off - with every function value computed in place by the code of the host-driven path:
+//   X = D1 + alpha D2 scaled to max|X| in [1, 2)            (k_form_pair_scaled, vi_fit.hip)
+//   (D1 + alpha D2) c' = yt, truncated                        (jacobi_system, vi_jacobi_device.h - the K3 kernel's body)
+//   C = V c'                                                  (k_v_vec)
+//   chi^2 = sum_p W_p (A_p . C - b_p)^2                       (k_chi2_part<256, 1> + k_chi2_sum: same chains, same tree)
+// and alpha = vi_exp10(x) (vi_exp10.h, the same function on the host).  The result is bit for bit what the host-driven
+// iteration gives from the same rotated system (tests/test_gpu_search_stages.py::test_device_brent_equals_host_brent); no
+// record waits for another, and the host sees one call.  The rotated system stays at the middle of the bracket (the host
+// path's re-basing next to the root needs eigenvectors and six matrix products per record).
+// A solve that the sweep cap ends before it converges makes the record leave with status 2: the host runs that record's
+// iteration itself (FitEngine: rotated-system solves that did not converge are solved again from X(alpha)).
+#include "vi_jacobi_device.h"
+#include "vi_exp10.h"
+
+#include <cstdlib>
+
+size_t vi_jacobi_lds_bytes(int N);
+size_t vi_jacobi_log_bytes(int N, int max_sweeps);
+bool vi_jacobi_supported(int N);
+double vi_floor_warm();                  // vi_fit.hip: absolute rotation floor of the rotated-system solves
+extern "C" int vi_max_sweeps(void);
+
+namespace {
+
+struct BrentState {
+    double xpre, xcur, xblk, fpre, fcur, fblk, spre, scur;
+    int it, funcalls, done, status;
+};
+
+// brentq_gen from the top of its loop to the next request (alpha_search.py: BrentBatch._top for one record); returns true
+// when the iteration has ended (root in xcur, other end in xblk).
+__device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rtol)
+{
+#pragma clang fp contract(off)
+    if (s.fpre != 0.0 && s.fcur != 0.0 && (signbit(s.fpre) != signbit(s.fcur))) {
+        s.xblk = s.xpre;
+        s.fblk = s.fpre;
+        s.spre = s.scur = s.xcur - s.xpre;
+    }
+    if (fabs(s.fblk) < fabs(s.fcur)) {
+        const double xp = s.xcur, xc = s.xblk, xb = s.xcur;
+        const double fp = s.fcur, fc = s.fblk, fb = s.fcur;
+        s.xpre = xp; s.xcur = xc; s.xblk = xb;
+        s.fpre = fp; s.fcur = fc; s.fblk = fb;
+    }
+    const double delta = (xtol + rtol * fabs(s.xcur)) / 2;
+    const double sbis = (s.xblk - s.xcur) / 2;
+    if (s.fcur == 0.0 || fabs(sbis) < delta) return true;
+    if (fabs(s.spre) > delta && fabs(s.fcur) < fabs(s.fpre)) {
+        double stry;
+        if (s.xpre == s.xblk) {
+            stry = -s.fcur * (s.xcur - s.xpre) / (s.fcur - s.fpre);                          // secant
+        } else {
+            const double dpre = (s.fpre - s.fcur) / (s.xpre - s.xcur);                       // inverse quadratic
+            const double dblk = (s.fblk - s.fcur) / (s.xblk - s.xcur);
+            stry = -s.fcur * (s.fblk * dblk - s.fpre * dpre) / (dblk * dpre * (s.fblk - s.fpre));
+        }
+        const double a = fabs(s.spre), b = 3 * fabs(sbis) - delta;
+        if (2 * fabs(stry) < (b < a ? b : a)) {
+            s.spre = s.scur;
+            s.scur = stry;
+        } else {
+            s.spre = sbis;
+            s.scur = sbis;
+        }
+    } else {
+        s.spre = sbis;
+        s.scur = sbis;
+    }
+    s.xpre = s.xcur;
+    s.fpre = s.fcur;
+    if (fabs(s.scur) > delta)
+        s.xcur += s.scur;
+    else
+        s.xcur += (sbis > 0 ? delta : -delta);
+    return false;
+}
+
+template <int IT>
+__global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
+    int N, int64_t P, int ntask, const double* __restrict__ D1, const double* __restrict__ D2, const double* __restrict__ yt,
+    const double* __restrict__ V, const double* __restrict__ At, const double* __restrict__ W, const double* __restrict__ b,
+    const int* __restrict__ t_rec, const int* __restrict__ t_slot, const double* __restrict__ t_xa,
+    const double* __restrict__ t_xb, const double* __restrict__ t_fa, const double* __restrict__ t_fb,
+    const double* __restrict__ t_nu, double rcond, double abs_floor, int max_sweeps, double xtol, double rtol, int maxiter,
+    int* __restrict__ queue, double* __restrict__ Xw, double2* __restrict__ logw, int64_t log_stride, double* __restrict__ cw,
+    double* __restrict__ o_root, double* __restrict__ o_other, int* __restrict__ o_iters, int* __restrict__ o_funcalls,
+    int* __restrict__ o_status, size_t lds_jacobi)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // behind the Jacobi kernel's LDS image: coefficients, chi^2 reduction, state
+    double* shC = reinterpret_cast<double*>(lds_raw + lds_jacobi);        // [N]
+    double* red = shC + ((N + 1) & ~1);                                    // [512]
+    double* part = red + 512;                                              // [64] partial sums of chi^2, one per block of 256 points
+    double* shd = part + 64;                                               // [16] max reduction
+    BrentState* st = reinterpret_cast<BrentState*>(shd + 16);
+    int* shi = reinterpret_cast<int*>(st + 1);                             // [0] task, [1] sweeps
+
+    const int tid = threadIdx.x, NT = blockDim.x, nw = NT >> 6;
+    const int NN = N * N;
+    double* Xs = Xw + (int64_t)blockIdx.x * NN;
+    double2* logp = logw + (int64_t)blockIdx.x * log_stride;
+    double* cp = cw + (int64_t)blockIdx.x * N;
+    const int nb = (int)((P + 255) / 256);
+
+    for (;;) {
+        if (tid == 0) shi[0] = atomicAdd(queue, 1);
+        __syncthreads();
+        const int task = shi[0];
+        if (task >= ntask) break;
+        const int64_t slot = t_slot[task], rec = t_rec[task];
+        const double nu = t_nu[task];
+        const double* D1s = D1 + slot * NN;
+        const double* D2s = D2 + slot * NN;
+        const double* Vs = V + slot * NN;
+        const double* Wr = W + rec * P;
+        const double* br = b + rec * P;
+        if (tid == 0) {
+            BrentState s;
+            s.xpre = t_xa[task]; s.xcur = t_xb[task]; s.fpre = t_fa[task]; s.fcur = t_fb[task];
+            s.xblk = s.fblk = s.spre = s.scur = 0.0;
+            s.it = 1; s.funcalls = 0; s.status = 0;
+            s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+            *st = s;
+        }
+        __syncthreads();
+        while (!st->done) {
+            const double alpha = vi_exp10(st->xcur);
+            // ---- X = f (D1 + alpha D2), f the power of two that brings max|X| into [1, 2)   (k_form_pair_scaled)
+            double mx = 0.0;
+            for (int e = tid; e < NN; e += NT) mx = fmax(mx, fabs(fma(alpha, D2s[e], D1s[e])));
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+            if ((tid & 63) == 0) shd[tid >> 6] = mx;
+            __syncthreads();
+            mx = 0.0;
+            for (int q = 0; q < nw; ++q) mx = fmax(mx, shd[q]);
+            int ex = 0;
+            double f = 1.0;
+            if (mx > 0.0 && mx < 1.7e308) {
+                (void)frexp(mx, &ex);
+                f = ldexp(1.0, 1 - ex);
+            }
+            for (int e = tid; e < NN; e += NT) Xs[e] = fma(alpha, D2s[e], D1s[e]) * f;
+            __syncthreads();
+            // ---- the truncated solve in the rotated system (the K3 kernel's body)
+            jacobi_system<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, nullptr, logp, max_sweeps, shi + 1,
+                              nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            // ---- C = V c'   (k_v_vec)
+            for (int k = tid; k < N; k += NT) red[k] = cp[k];
+            __syncthreads();
+            for (int r = tid; r < N; r += NT) {
+                double acc = 0.0;
+                for (int k = 0; k < N; ++k) acc = fma(Vs[(int64_t)k * N + r], red[k], acc);
+                shC[r] = acc;
+            }
+            __syncthreads();
+            // ---- chi^2   (k_chi2_part<256, 1>: one fma chain over n per data point, a fixed tree over the 256 points of a
+            //      block; k_chi2_sum: the blocks in order).  Two blocks of points at a time, one per half of 512 threads.
+            for (int b0 = 0; b0 < nb; b0 += 2) {
+                const int half = tid >> 8, t = tid & 255;
+                const int blk = b0 + half;
+                double v = 0.0;
+                if (tid < 512 && blk < nb) {
+                    const int64_t p = (int64_t)blk * 256 + t;
+                    if (p < P) {
+                        double acc = 0.0;
+#pragma unroll 8
+                        for (int n = 0; n < N; ++n) acc = fma(At[(int64_t)n * P + p], shC[n], acc);
+                        const double d = acc - br[p];
+                        v = d * d * Wr[p];
+                    }
+                }
+                if (tid < 512) red[tid] = v;
+                __syncthreads();
+                for (int h = 128; h > 0; h >>= 1) {
+                    if (tid < 512 && t < h) red[tid] += red[tid + h];
+                    __syncthreads();
+                }
+                if (tid < 512 && t == 0 && blk < nb) part[blk] = red[tid];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                double chi = 0.0;
+                for (int j = 0; j < nb; ++j) chi += part[j];
+                BrentState s = *st;
+                if (shi[1] > max_sweeps) {
+                    s.status = 2;                    // the solve did not converge: this record goes back to the host
+                    s.done = 1;
+                } else {
+                    s.fcur = chi - nu;
+                    s.funcalls += 1;
+                    s.it += 1;
+                    if (s.it > maxiter) {
+                        s.status = 3;
+                        s.done = 1;
+                    } else {
+                        s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+                    }
+                }
+                *st = s;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            o_root[task] = st->xcur;
+            o_other[task] = st->xblk;
+            o_iters[task] = st->it;
+            o_funcalls[task] = st->funcalls;
+            o_status[task] = st->status;
+        }
+        __syncthreads();
+    }
+}
+
+void brent_geometry(int N, int& threads, int& it)
+{
+    const int M = ((N + 3) & ~3) / 4;
+    const int nsb = M * (M - 1) / 2;
+    if (nsb <= 768) {
+        it = 1;
+        threads = ((nsb + 63) / 64) * 64;
+        if (threads < 512) threads = 512;          // the chi^2 pass wants two blocks of 256 points
+    } else {
+        threads = 512;
+        it = (nsb + 511) / 512;
+    }
+}
+
+}  // namespace
+
+extern "C" int vi_exp10_f64(const double* x, double* out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = vi_exp10(x[i]);
+    return VI_OK;
+}
+
+// Brent's iteration (interpolate.py:214) of ntask records in one launch, each in the rotated system of its slot
+// (vi_warm_prepare_f64).  Task arrays are device arrays of length ntask; outputs likewise: root and the other end of the
+// final bracket (log10 alpha), iterations and function calls as brentq counts them, status 0 = converged, 2 = a solve hit the
+// sweep cap (the caller runs that record's iteration on the host), 3 = maxiter exceeded.
+extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
+                                 const double* d_yt, const double* d_V, const double* d_At, const double* d_W,
+                                 const double* d_b, const int32_t* d_rec, const int32_t* d_slot, const double* d_xa,
+                                 const double* d_xb, const double* d_fa, const double* d_fb, const double* d_nu, double rcond,
+                                 double* d_root, double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status)
+{
+    const double abs_floor = vi_floor_warm();
+    const int max_sweeps = vi_max_sweeps();
+    VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_At && d_W && d_b && d_rec && d_slot && d_xa && d_xb && d_fa && d_fb && d_nu &&
+                   d_root && d_other && d_iters && d_funcalls && d_status, "null argument");
+    VI_REQUIRE(ntask >= 0 && N > 0 && P > 0, "bad size");
+    if (ntask == 0) return VI_OK;
+    if (!vi_jacobi_supported(N)) {
+        vi_set_error("vi_brent_warm_f64: N=%d outside the in-LDS Jacobi range", N);
+        return VI_ERR_UNSUPPORTED;
+    }
+    VI_REQUIRE((P + 255) / 256 <= 64, "more than 16384 data points per record");
+    VI_HIP(hipSetDevice(c->device));
+    int threads, it;
+    brent_geometry(N, threads, it);
+    const int64_t nwg = ntask < c->n_cu ? ntask : c->n_cu;
+    const size_t logb = vi_jacobi_log_bytes(N, max_sweeps);
+    void* ws = nullptr;
+    int rc = vi_ctx_workspace(c, (size_t)nwg * (logb + (size_t)(N * N + N) * sizeof(double)) + 256, &ws);
+    if (rc != VI_OK) return rc;
+    double2* logw = (double2*)ws;
+    double* Xw = (double*)((char*)ws + (size_t)nwg * logb);
+    double* cw = Xw + (size_t)nwg * N * N;
+    int* queue = (int*)(cw + (size_t)nwg * N + 1);
+    VI_HIP(hipMemsetAsync(queue, 0, sizeof(int), c->stream));
+    const size_t ldsj = (vi_jacobi_lds_bytes(N) + 15) & ~(size_t)15;
+    const size_t shm = ldsj + ((size_t)((N + 1) & ~1) + 512 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
+#define VI_B(ITV)                                                                                                             \
+    do {                                                                                                                      \
+        VI_HIP(hipFuncSetAttribute((const void*)k_brent_warm<ITV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));    \
+        hipLaunchKernelGGL(k_brent_warm<ITV>, dim3((unsigned)nwg), dim3(threads), shm, c->stream, N, P, (int)ntask, d_D1, d_D2, \
+                           d_yt, d_V, d_At, d_W, d_b, d_rec, d_slot, d_xa, d_xb, d_fa, d_fb, d_nu, rcond, abs_floor,          \
+                           (int)max_sweeps, 2e-12, 4 * 2.220446049250313e-16, 100, queue, Xw, logw,                           \
+                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj);      \
+    } while (0)
+    if (it <= 1) VI_B(1);
+    else if (it <= 2) VI_B(2);
+    else VI_B(3);
+#undef VI_B
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}

@@ -935,6 +935,7 @@ extern "C" int vi_warm_prepare_f64(vi_ctx* c, int64_t B, int32_t N, const double
 // and the three products - only the one the walk then points at.
 extern "C" size_t vi_rotation_log_bytes(int32_t N) { return log_record_bytes(N); }
 extern "C" int vi_max_sweeps(void) { return JACOBI_MAX_SWEEPS; }
+double vi_floor_warm() { return JACOBI_FLOOR_WARM; }
 
 extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                                 const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,

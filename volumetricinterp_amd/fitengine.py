@@ -48,6 +48,9 @@ _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.V
 _lib._sig('vi_basis_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_max_sweeps', C.c_int)
+_lib._sig('vi_brent_warm_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, C.c_int64, *([_lib.VOIDP] * 14), C.c_double,
+          *([_lib.VOIDP] * 5))
+_lib._sig('vi_exp10_f64', C.c_int, _lib.VOIDP, _lib.VOIDP, C.c_int64)
 _lib._sig('vi_reg_floor_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_rotation_log_bytes', C.c_size_t, C.c_int32)
 _lib._sig('vi_decompose_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
@@ -65,7 +68,7 @@ _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_qr_similarity_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP)
-_lib.EXPORTS += ['vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib.EXPORTS += ['vi_brent_warm_f64', 'vi_exp10_f64', 'vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -441,7 +444,7 @@ class FitEngine(object):
             back = np.zeros(3)                  # chi^2, an internal word, the sweep count (low 32 bits)
             r = int(rec[0])
             _lib.check(_lib.lib.vi_warm_chi2_one_f64(self.ctx.handle, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr,
-                                                     self._warm_slot[r], float(np.power(10., log10a[0])), EPS,
+                                                     self._warm_slot[r], self._exp10(log10a[0]), EPS,
                                                      self.At.ptr, r, self.dW.ptr, self.db.ptr, scratch.ptr,
                                                      back.ctypes.data_as(C.POINTER(C.c_double))), 'vi_warm_chi2_one_f64')
             self.stats['solves'] += 1
@@ -459,6 +462,13 @@ class FitEngine(object):
             al = {n: (np.power(10., log10a) if n == name else np.zeros(B)) for n in self.regularization_list}
             return self.chi2_batch(rec, al)
         alpha = np.power(10., log10a)
+        if not is_int.all():
+            # the root finder's abscissae: 10^x by the routine the device-side iteration uses (csrc/vi_exp10.h), so that
+            # host-driven and device-side iterations form the same alpha from the same x
+            ni = np.ascontiguousarray(log10a[~is_int])
+            out_ = np.empty_like(ni)
+            _lib.check(_lib.lib.vi_exp10_f64(ni.ctypes.data_as(_lib.VOIDP), out_.ctypes.data_as(_lib.VOIDP), len(ni)), 'vi_exp10_f64')
+            alpha[~is_int] = out_
         if (self.T == 1 and B >= 8 and is_int.all() and not forced.any() and not self._warm_slot and not self._spec_slot
                 and os.environ.get('VINTERP_SPECULATE', '1') != '0'):
             return self._walk_with_speculative_bases(rec, log10a, alpha, name, trace)
@@ -608,6 +618,67 @@ class FitEngine(object):
         self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
 
+    def device_brent_enabled(self):
+        """Brent's iteration of the whole batch in one launch (vi_brent_warm_f64, csrc/vi_brent.hip) instead of one round of
+        launches per iterate.  OFF unless VINTERP_DEVICE_BRENT=1: the kernel reproduces the host-driven iteration bit for bit
+        (tests/test_gpu_search_stages.py) but keeps every record's rotated system at the middle of its bracket, and without
+        the re-basing next to the root Brent needs 25 iterations per record instead of 15 and every iterate more sweeps:
+        measured on 1000 records 546 ms against 520 in one pipeline, 522 against 446 in four."""
+        if os.environ.get('VINTERP_DEVICE_BRENT', '0') != '1':
+            return False
+        return self.warm_enabled() and len(self.regularization_list) == 1 and self.T >= 2
+
+    def _device_brent(self, recs, brackets, name):
+        """Brent's iteration for the records `recs` (brackets: dicts with alpha, alpha0, val, val0, nu) on the device.
+        Rotated systems are set up at the middle of each record's unit bracket, as the host path does; returns one
+        (root, iterations, funcalls, other_end) per record, None where the kernel gave up (a solve ended by the sweep cap)."""
+        N, h, n = self.N, self.ctx.handle, len(recs)
+        recs = [int(r) for r in recs]
+        need = [r for r in recs if r not in self._warm_slot]
+        if need:
+            mids = {r: math.floor(min(b['alpha'], b['alpha0'])) + 0.5 for r, b in zip(recs, brackets)}
+            scratchC = self._buf('wp_scratchC', (len(need), N))
+            scratchR = self._buf('wp_scratchR', (len(need),), np.int32)
+            for r in need:
+                self._basis_x[r] = mids[r]
+            self._warm_prepare('w_', self._warm_slot, need, [float(np.power(10., mids[r])) for r in need], name,
+                               scratchC.ptr, scratchR.ptr)
+            self.stats['solves'] += len(need)
+        dV, dD1, dD2, dyt = self._warm_buffers('w_')
+        up = lambda key, a, dt: self._buf('db_' + key, (n,), dt).upload(np.asarray(a, dtype=dt))      # noqa: E731
+        drec, dslot = up('rec', recs, np.int32), up('slot', [self._warm_slot[r] for r in recs], np.int32)
+        dxa, dxb = up('xa', [b['alpha'] for b in brackets], np.float64), up('xb', [b['alpha0'] for b in brackets], np.float64)
+        dfa, dfb = up('fa', [b['val'] for b in brackets], np.float64), up('fb', [b['val0'] for b in brackets], np.float64)
+        dnu = up('nu', [b['nu'] for b in brackets], np.float64)
+        droot, dother = self._buf('db_root', (n,)), self._buf('db_other', (n,))
+        dit, dfc, dst = (self._buf('db_' + k, (n,), np.int32) for k in ('it', 'fc', 'st'))
+        _lib.check(_lib.lib.vi_brent_warm_f64(h, n, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, self.At.ptr, self.dW.ptr,
+                                              self.db.ptr, drec.ptr, dslot.ptr, dxa.ptr, dxb.ptr, dfa.ptr, dfb.ptr, dnu.ptr,
+                                              EPS, droot.ptr, dother.ptr, dit.ptr, dfc.ptr, dst.ptr), 'vi_brent_warm_f64')
+
+        def down(d, dt):
+            a = np.empty(n, dtype=dt)
+            _lib.check(_lib.lib.vi_d2h(h, a.ctypes.data_as(_lib.VOIDP), d.ptr, a.nbytes), 'd2h')
+            return a
+        root, other, its, fcs, sts = down(droot, np.float64), down(dother, np.float64), down(dit, np.int32), \
+            down(dfc, np.int32), down(dst, np.int32)
+        if np.any(sts == 3):
+            raise RuntimeError('Failed to converge after %d iterations.' % alpha_search.MAXITER)
+        self.stats['solves'] += int(fcs.sum())
+        self.stats['launches'] += 1
+        self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + int(fcs.sum())
+        self.stats['device_brent_records'] = self.stats.get('device_brent_records', 0) + int((sts == 0).sum())
+        if np.any(sts == 2):
+            self.stats['unconverged_resolved'] = self.stats.get('unconverged_resolved', 0) + int((sts == 2).sum())
+        return [(float(root[j]), int(its[j]), int(fcs[j]), float(other[j])) if sts[j] == 0 else None for j in range(n)]
+
+    @staticmethod
+    def _exp10(x):
+        """10^x for one root-finder abscissa by the library's routine (see _chi2_batch_search_raw)."""
+        a, o = np.array([float(x)]), np.empty(1)
+        _lib.check(_lib.lib.vi_exp10_f64(a.ctypes.data_as(_lib.VOIDP), o.ctypes.data_as(_lib.VOIDP), 1), 'vi_exp10_f64')
+        return float(o[0])
+
     def max_sweeps(self):
         v = getattr(self, '_max_sweeps', None)
         if v is None:
@@ -753,9 +824,13 @@ class FitEngine(object):
             refine = bool(self._ref_rec is not None and self.shared_walk_enabled() and not cold)
             # Brent's iteration on arrays pays from a dozen records on (NumPy's per-call overhead on arrays of one or two
             # elements is several times the coroutine's step)
+            solver = None
+            if self.device_brent_enabled() and not cold and not multisection:
+                def solver(recs, brs, _name=name):
+                    return self._device_brent(recs, brs, _name)
             alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
                                                                    multisection=multisection, refine=refine,
-                                                                   vector_brent=T >= 16)
+                                                                   vector_brent=T >= 16, brent_solver=solver)
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
