@@ -261,11 +261,17 @@ int  vi_warm_chi2_one_f64(vi_ctx* ctx, int32_t N, int64_t P, const double* d_D1,
  * records in ONE launch: a workgroup owns a record from its unit bracket [xa, xb] (values fa, fb) to its root, every
  * function value computed in place in the rotated system of the record's slot (vi_warm_prepare_f64) by the code of
  * vi_warm_solve_f64 + vi_chi2_f64, alpha = vi_exp10 (below).  Device arrays of length ntask in and out: root and other end
- * of the final bracket (log10 alpha), iterations / function calls as brentq counts them, status 0 = converged, 2 = a solve
+ * of the final bracket (log10 alpha), iterations / function calls as brentq counts them, status (low byte; bits 8 and up
+ * count how often the record's rotated system was re-based) 0 = converged, 2 = a solve
  * was ended by the sweep cap (run that record's iteration on the host), 3 = more than 100 iterations.  Bit for bit the
- * result of the host-driven iteration from the same rotated system. */
-int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
-                       const double* d_yt, const double* d_V, const double* d_At, const double* d_W, const double* d_b,
+ * result of the host-driven iteration from the same rotated system.
+ * The rotated systems (d_D1, d_D2, d_yt, d_V, by slot) are MOVED next to the root as the host path does
+ * (vi_warm_rebase_f64) by the rule in h_rebase (host, 8 doubles: number of thresholds, up to four thresholds in decades
+ * between consecutive abscissae, then the late move: after so many requests, within so many decades, enabled) - from
+ * d_AWA, d_y (by record) and d_R. */
+int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt,
+                       double* d_V, const double* d_AWA, const double* d_R, const double* d_y, const double* h_rebase,
+                       const double* d_At, const double* d_W, const double* d_b,
                        const int32_t* d_rec, const int32_t* d_slot, const double* d_xa, const double* d_xb,
                        const double* d_fa, const double* d_fb, const double* d_nu, double rcond, double* d_root,
                        double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status);

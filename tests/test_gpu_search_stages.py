@@ -273,30 +273,33 @@ def test_qr_similarity_preconditioner():
 
 def test_device_brent_equals_host_brent(monkeypatch):
     """vi_brent_warm_f64 (csrc/vi_brent.hip): Brent's iteration of a whole batch in one launch, a workgroup per record.  The
-    same records through the host-driven iteration from the same rotated systems (VINTERP_DEVICE_BRENT=0 with the re-basing
-    off, which the device path does not do) give the same alpha, chi^2 and coefficients BIT FOR BIT, the same iteration
-    counts, and the same verdicts of the consistency guard - at the benchmarked order and at a small one."""
+    same records through the host-driven iteration (VINTERP_DEVICE_BRENT=0) - rotated systems set up at the middle of the
+    bracket, moved next to the root when the iterates cluster, moved again for the records that bisect a jump - give the same
+    alpha, chi^2 and coefficients BIT FOR BIT, the same iteration counts and final brackets: the kernel runs the host path's
+    arithmetic (the K3 body, the products of the re-basing, chi^2, 10^x) in the host path's order.  Also with the re-basing
+    switched off on both sides."""
     from volumetricinterp_amd import synth
-    for cfg, geom, T in ((CFG144, synth.GEOM_C2, 24),):
-        m, ctx, eng, A, _ = _engine(cfg, geom)
-        P = A.shape[0]
-        value, error = synth.synth_records(A, T, seed0=8000)
-        W = error**-2.
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 24
+    value, error = synth.synth_records(A, T, seed0=8000)
+    W = error**-2.
+    for rebase in ('1', '0'):
+        monkeypatch.setenv('VINTERP_REBASE', rebase)
         monkeypatch.setenv('VINTERP_DEVICE_BRENT', '1')
+        n0 = eng.stats.get('device_brent_records', 0)
         dev = eng.fit(W, value, [P] * T)
         ndev = eng.stats.get('device_brent_records', 0)
-        assert ndev >= T // 2
+        assert ndev - n0 >= T // 2
         monkeypatch.setenv('VINTERP_DEVICE_BRENT', '0')
-        monkeypatch.setenv('VINTERP_REBASE', '0')
         host = eng.fit(W, value, [P] * T)
         assert eng.stats.get('device_brent_records', 0) == ndev            # none added: the host iterated
         monkeypatch.delenv('VINTERP_REBASE')
         monkeypatch.delenv('VINTERP_DEVICE_BRENT')
         for t in range(T):
             a1, a2 = dev['reg_params'][t]['curvature'], host['reg_params'][t]['curvature']
-            assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (t, a1, a2)
-            assert np.array_equal(dev['Coeffs'][t], host['Coeffs'][t], equal_nan=True), t
-            assert dev['chi_sq'][t] == host['chi_sq'][t] or np.isnan(a1)
             i1, i2 = dev['search']['curvature']['info'][t], host['search']['curvature']['info'][t]
-            assert i1.get('iterations') == i2.get('iterations') and i1.get('other_end') == i2.get('other_end'), (t, i1, i2)
-        eng.close()
+            assert i1.get('iterations') == i2.get('iterations') and i1.get('other_end') == i2.get('other_end'), (rebase, t, i1, i2)
+            assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (rebase, t, a1, a2)
+            assert np.array_equal(dev['Coeffs'][t], host['Coeffs'][t], equal_nan=True), (rebase, t)
+            assert dev['chi_sq'][t] == host['chi_sq'][t] or np.isnan(a1)
+    eng.close()

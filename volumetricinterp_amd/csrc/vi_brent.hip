@@ -21,6 +21,7 @@
 // A solve that the sweep cap ends before it converges makes the record leave with status 2: the host runs that record's
 // iteration itself (FitEngine: rotated-system solves that did not converge are solved again from X(alpha)).
 #include "vi_jacobi_device.h"
+#include "vi_gemm_device.h"
 #include "vi_exp10.h"
 
 #include <cstdlib>
@@ -35,8 +36,36 @@ namespace {
 
 struct BrentState {
     double xpre, xcur, xblk, fpre, fcur, fblk, spre, scur;
+    double last_x;                    // the record's previous abscissa (NaN: none yet) - FitEngine._last_x
     int it, funcalls, done, status;
+    int nreq, rebased, rebase_now;    // FitEngine._nreq, ._rebased; this iterate moves the rotated system to its alpha
 };
+
+// The re-basing rule of the host path (FitEngine._wants_rebase), looking at the record's own abscissae only.
+struct RebaseRule {
+    double sched[4];                  // k-th move: the first time two consecutive abscissae lie closer than sched[k]
+    int nsched;
+    int again_after;                  // one more move after this many requests ...
+    double again_within;              // ... when two consecutive abscissae lie closer than this (records bisecting a jump)
+    int again_on;
+};
+
+__device__ __forceinline__ void rebase_decide(BrentState& s, const RebaseRule& rr)
+{
+    const double x = s.xcur;
+    bool rb = false;
+    if (s.last_x == s.last_x) {                                   // not NaN
+        const double d = fabs(x - s.last_x);
+        if (s.rebased < rr.nsched)
+            rb = d < rr.sched[s.rebased];
+        else
+            rb = rr.again_on && s.rebased == rr.nsched && s.nreq >= rr.again_after && d < rr.again_within;
+    }
+    if (rb) s.rebased += 1;
+    s.rebase_now = rb ? 1 : 0;
+    s.last_x = x;
+    s.nreq += 1;
+}
 
 // brentq_gen from the top of its loop to the next request (alpha_search.py: BrentBatch._top for one record); returns true
 // when the iteration has ended (root in xcur, other end in xblk).
@@ -89,8 +118,9 @@ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rto
 
 template <int IT>
 __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
-    int N, int64_t P, int ntask, const double* __restrict__ D1, const double* __restrict__ D2, const double* __restrict__ yt,
-    const double* __restrict__ V, const double* __restrict__ At, const double* __restrict__ W, const double* __restrict__ b,
+    int N, int64_t P, int ntask, double* D1, double* D2, double* yt, double* V, const double* __restrict__ AWA,
+    const double* __restrict__ Rm, const double* __restrict__ ysrc, RebaseRule rr, double* __restrict__ VwW, double* __restrict__ VnW,
+    const double* __restrict__ At, const double* __restrict__ W, const double* __restrict__ b,
     const int* __restrict__ t_rec, const int* __restrict__ t_slot, const double* __restrict__ t_xa,
     const double* __restrict__ t_xb, const double* __restrict__ t_fa, const double* __restrict__ t_fb,
     const double* __restrict__ t_nu, double rcond, double abs_floor, int max_sweeps, double xtol, double rtol, int maxiter,
@@ -105,14 +135,17 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     double* part = red + 512;                                              // [64] partial sums of chi^2, one per block of 256 points
     double* shd = part + 64;                                               // [16] max reduction
     BrentState* st = reinterpret_cast<BrentState*>(shd + 16);
-    int* shi = reinterpret_cast<int*>(st + 1);                             // [0] task, [1] sweeps
+    int* shi = reinterpret_cast<int*>(st + 1);                             // [0] task, [1] sweeps, [2] rounds of the last solve
 
     const int tid = threadIdx.x, NT = blockDim.x, nw = NT >> 6;
     const int NN = N * N;
     double* Xs = Xw + (int64_t)blockIdx.x * NN;
     double2* logp = logw + (int64_t)blockIdx.x * log_stride;
     double* cp = cw + (int64_t)blockIdx.x * N;
+    double* VwS = VwW + (int64_t)blockIdx.x * NN;                          // eigenvectors of a rotated system / product scratch
+    double* VnS = VnW + (int64_t)blockIdx.x * NN;                          // the new basis V Vw
     const int nb = (int)((P + 255) / 256);
+    const int lane = tid & 63, wave = tid >> 6;
 
     for (;;) {
         if (tid == 0) shi[0] = atomicAdd(queue, 1);
@@ -121,9 +154,9 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
         if (task >= ntask) break;
         const int64_t slot = t_slot[task], rec = t_rec[task];
         const double nu = t_nu[task];
-        const double* D1s = D1 + slot * NN;
-        const double* D2s = D2 + slot * NN;
-        const double* Vs = V + slot * NN;
+        double* D1s = D1 + slot * NN;
+        double* D2s = D2 + slot * NN;
+        double* Vs = V + slot * NN;
         const double* Wr = W + rec * P;
         const double* br = b + rec * P;
         if (tid == 0) {
@@ -131,7 +164,10 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             s.xpre = t_xa[task]; s.xcur = t_xb[task]; s.fpre = t_fa[task]; s.fcur = t_fb[task];
             s.xblk = s.fblk = s.spre = s.scur = 0.0;
             s.it = 1; s.funcalls = 0; s.status = 0;
+            s.last_x = __builtin_nan("");
+            s.nreq = 0; s.rebased = 0; s.rebase_now = 0;
             s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+            if (!s.done) rebase_decide(s, rr);
             *st = s;
         }
         __syncthreads();
@@ -155,7 +191,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             __syncthreads();
             // ---- the truncated solve in the rotated system (the K3 kernel's body)
             jacobi_system<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, nullptr, logp, max_sweeps, shi + 1,
-                              nullptr, 0, nullptr, nullptr);
+                              nullptr, 0, shi + 2, nullptr);
             __syncthreads();
             // ---- C = V c'   (k_v_vec)
             for (int k = tid; k < N; k += NT) red[k] = cp[k];
@@ -212,13 +248,43 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                 *st = s;
             }
             __syncthreads();
+            if (st->rebase_now && st->status == 0 && !st->done) {
+                // ---- move the rotated system to this iterate's alpha (vi_warm_rebase_f64): eigenvectors Vw of the rotated
+                //      system out of the rotation log of the solve just done, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V,
+                //      yt = V^T y from the untransformed matrices - the host path's kernels, the host path's order
+                const int64_t nround = shi[2];
+                for (int col0 = wave * 4; col0 < N; col0 += nw * 4) jacobi_vector_strip<4>(N, logp, nround, col0, lane, VwS);
+                __syncthreads();
+                double* ldsg = reinterpret_cast<double*>(lds_raw);
+                wg_gemm<false>(N, Vs, VwS, VnS, ldsg);
+                for (int e = tid; e < NN; e += NT) Vs[e] = VnS[e];
+                __syncthreads();
+                wg_gemm<false>(N, AWA + rec * NN, VnS, VwS, ldsg);
+                wg_gemm<true>(N, VnS, VwS, D1s, ldsg);
+                wg_gemm<false>(N, Rm, VnS, VwS, ldsg);
+                wg_gemm<true>(N, VnS, VwS, D2s, ldsg);
+                const double* yr = ysrc + rec * N;
+                for (int k = wave; k < N; k += nw) {                 // k_vt_vec_slot
+                    double acc = 0.0;
+                    for (int r = lane; r < N; r += 64) acc = fma(VnS[(int64_t)k * N + r], yr[r], acc);
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_down(acc, o2);
+                    if (lane == 0) yt[slot * N + k] = acc;
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && !st->done) {
+                BrentState s = *st;
+                rebase_decide(s, rr);
+                *st = s;
+            }
+            __syncthreads();
         }
         if (tid == 0) {
             o_root[task] = st->xcur;
             o_other[task] = st->xblk;
             o_iters[task] = st->it;
             o_funcalls[task] = st->funcalls;
-            o_status[task] = st->status;
+            o_status[task] = st->status | (st->rebased << 8);      // low byte: the status; above it: how often the system moved
         }
         __syncthreads();
     }
@@ -248,17 +314,20 @@ extern "C" int vi_exp10_f64(const double* x, double* out, int64_t n)
 
 // Brent's iteration (interpolate.py:214) of ntask records in one launch, each in the rotated system of its slot
 // (vi_warm_prepare_f64).  Task arrays are device arrays of length ntask; outputs likewise: root and the other end of the
-// final bracket (log10 alpha), iterations and function calls as brentq counts them, status 0 = converged, 2 = a solve hit the
+// final bracket (log10 alpha), iterations and function calls as brentq counts them, status (low byte; the bits above count the
+// record's re-basings) 0 = converged, 2 = a solve hit the
 // sweep cap (the caller runs that record's iteration on the host), 3 = maxiter exceeded.
-extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P, const double* d_D1, const double* d_D2,
-                                 const double* d_yt, const double* d_V, const double* d_At, const double* d_W,
+extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt,
+                                 double* d_V, const double* d_AWA, const double* d_R, const double* d_y,
+                                 const double* h_rebase /* 8 doubles: nsched, sched[4], again_after, again_within, again_on */,
+                                 const double* d_At, const double* d_W,
                                  const double* d_b, const int32_t* d_rec, const int32_t* d_slot, const double* d_xa,
                                  const double* d_xb, const double* d_fa, const double* d_fb, const double* d_nu, double rcond,
                                  double* d_root, double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status)
 {
     const double abs_floor = vi_floor_warm();
     const int max_sweeps = vi_max_sweeps();
-    VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_At && d_W && d_b && d_rec && d_slot && d_xa && d_xb && d_fa && d_fb && d_nu &&
+    VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_AWA && d_R && d_y && h_rebase && d_At && d_W && d_b && d_rec && d_slot && d_xa && d_xb && d_fa && d_fb && d_nu &&
                    d_root && d_other && d_iters && d_funcalls && d_status, "null argument");
     VI_REQUIRE(ntask >= 0 && N > 0 && P > 0, "bad size");
     if (ntask == 0) return VI_OK;
@@ -273,22 +342,33 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
     const int64_t nwg = ntask < c->n_cu ? ntask : c->n_cu;
     const size_t logb = vi_jacobi_log_bytes(N, max_sweeps);
     void* ws = nullptr;
-    int rc = vi_ctx_workspace(c, (size_t)nwg * (logb + (size_t)(N * N + N) * sizeof(double)) + 256, &ws);
+    int rc = vi_ctx_workspace(c, (size_t)nwg * (logb + (size_t)(3 * N * N + N) * sizeof(double)) + 256, &ws);
     if (rc != VI_OK) return rc;
     double2* logw = (double2*)ws;
     double* Xw = (double*)((char*)ws + (size_t)nwg * logb);
-    double* cw = Xw + (size_t)nwg * N * N;
+    double* VwW = Xw + (size_t)nwg * N * N;
+    double* VnW = VwW + (size_t)nwg * N * N;
+    double* cw = VnW + (size_t)nwg * N * N;
+    RebaseRule rr;
+    rr.nsched = (int)h_rebase[0];
+    if (rr.nsched < 0 || rr.nsched > 4) { vi_set_error("vi_brent_warm_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
+    for (int i = 0; i < 4; ++i) rr.sched[i] = h_rebase[1 + i];
+    rr.again_after = (int)h_rebase[5];
+    rr.again_within = h_rebase[6];
+    rr.again_on = (int)h_rebase[7];
     int* queue = (int*)(cw + (size_t)nwg * N + 1);
     VI_HIP(hipMemsetAsync(queue, 0, sizeof(int), c->stream));
     const size_t ldsj = (vi_jacobi_lds_bytes(N) + 15) & ~(size_t)15;
-    const size_t shm = ldsj + ((size_t)((N + 1) & ~1) + 512 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
+    size_t ldsj2 = wg_gemm_lds_doubles(N) * sizeof(double);
+    const size_t ldsj_eff = ldsj > ldsj2 ? ldsj : ((ldsj2 + 15) & ~(size_t)15);
+    const size_t shm = ldsj_eff + ((size_t)((N + 1) & ~1) + 512 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
 #define VI_B(ITV)                                                                                                             \
     do {                                                                                                                      \
         VI_HIP(hipFuncSetAttribute((const void*)k_brent_warm<ITV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));    \
         hipLaunchKernelGGL(k_brent_warm<ITV>, dim3((unsigned)nwg), dim3(threads), shm, c->stream, N, P, (int)ntask, d_D1, d_D2, \
-                           d_yt, d_V, d_At, d_W, d_b, d_rec, d_slot, d_xa, d_xb, d_fa, d_fb, d_nu, rcond, abs_floor,          \
+                           d_yt, d_V, d_AWA, d_R, d_y, rr, VwW, VnW, d_At, d_W, d_b, d_rec, d_slot, d_xa, d_xb, d_fa, d_fb, d_nu, rcond, abs_floor,          \
                            (int)max_sweeps, 2e-12, 4 * 2.220446049250313e-16, 100, queue, Xw, logw,                           \
-                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj);      \
+                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj_eff);  \
     } while (0)
     if (it <= 1) VI_B(1);
     else if (it <= 2) VI_B(2);

@@ -3,6 +3,7 @@
 // (interpolate.py:255-259).  The basis matrix is shared by all records (geometry is per file, not per
 // record), so T records become one strided-batched contraction instead of T x (#alpha) einsums.
 #include "vi_common.h"
+#include "vi_gemm_device.h"
 
 #include <rocsolver/rocsolver.h>
 
@@ -531,6 +532,33 @@ int gemm_groups(vi_ctx* c, rocblas_operation ta, rocblas_operation tb, int m, in
     for (int64_t g0 = 0; g0 < group_pad(count); g0 += GEMM_GROUP)
         VI_ROCBLAS(rocblas_dgemm_batched(c->blas, ta, tb, m, n, k, &one, pA + g0, lda, pB + g0, ldb, &zero,
                                          (double* const*)(pC + g0), ldc, GEMM_GROUP));
+    return VI_OK;
+}
+
+// C[i] = op(A[i]) B[i] for `count` N x N column-major matrices, one workgroup each, by wg_gemm (vi_gemm_device.h): the
+// products of the re-basing, whose bits the device-side search (k_brent_warm) must reproduce.
+template <bool TA>
+__global__ __launch_bounds__(640) void k_wg_gemm(int N, const double* const* __restrict__ pA, const double* const* __restrict__ pB,
+                                                 const double* const* __restrict__ pC)
+{
+    extern __shared__ __align__(16) double shg[];
+    wg_gemm<TA>(N, pA[blockIdx.x], pB[blockIdx.x], const_cast<double*>(pC[blockIdx.x]), shg);
+}
+
+int wg_gemm_batched(vi_ctx* c, bool ta, int N, const double** pA, const double** pB, const double** pC, int64_t count)
+{
+    const size_t shm = wg_gemm_lds_doubles(N) * sizeof(double);
+    const int nt = (N + 5) / 6;
+    int threads = ((nt * nt + 63) / 64) * 64;
+    if (threads > 640) threads = 640;
+    if (ta) {
+        VI_HIP(hipFuncSetAttribute((const void*)k_wg_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_wg_gemm<true>, dim3((unsigned)count), dim3(threads), shm, c->stream, N, pA, pB, pC);
+    } else {
+        VI_HIP(hipFuncSetAttribute((const void*)k_wg_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_wg_gemm<false>, dim3((unsigned)count), dim3(threads), shm, c->stream, N, pA, pB, pC);
+    }
+    VI_HIP(hipGetLastError());
     return VI_OK;
 }
 }  // namespace
@@ -1226,8 +1254,8 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t 
         if ((rc = group_ptrs(c, bc, d_V, NN, nullptr, 0, pVold, slotc)) != VI_OK) return rc;
         if ((rc = group_ptrs(c, bc, Vw, NN, scrA, NN, pVw)) != VI_OK) return rc;
         if ((rc = group_ptrs(c, bc, Vn, NN, scrB, NN, pVn)) != VI_OK) return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pVold, N, pVw, N, pVn, N, bc)) != VI_OK)
-            return rc;
+        // (own products with a fixed summation order, not the library's: k_brent_warm re-bases with the same code)
+        if ((rc = wg_gemm_batched(c, false, N, pVold, pVw, pVn, bc)) != VI_OK) return rc;
         hipLaunchKernelGGL(k_scatter_mat, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, Vn, slotc, d_V);
         hipLaunchKernelGGL(k_form_system, dim3((unsigned)bc), dim3(256), 0, c->stream, NN, d_AWA, recc, nullptr, nullptr, X);
         VI_HIP(hipGetLastError());
@@ -1236,14 +1264,10 @@ extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t 
         if ((rc = group_ptrs(c, bc, d_D1, NN, scrB, NN, pD1, slotc)) != VI_OK) return rc;
         if ((rc = group_ptrs(c, bc, d_D2, NN, scrB, NN, pD2, slotc)) != VI_OK) return rc;
         // (pVn reads Vn, which still holds V_new; pVw now names the product buffer)
-        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pX, N, pVn, N, pVw, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pVn, N, pVw, N, pD1, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_none, rocblas_operation_none, N, N, N, pR, N, pVn, N, pVw, N, bc)) != VI_OK)
-            return rc;
-        if ((rc = gemm_groups(c, rocblas_operation_transpose, rocblas_operation_none, N, N, N, pVn, N, pVw, N, pD2, N, bc)) != VI_OK)
-            return rc;
+        if ((rc = wg_gemm_batched(c, false, N, pX, pVn, pVw, bc)) != VI_OK) return rc;
+        if ((rc = wg_gemm_batched(c, true, N, pVn, pVw, pD1, bc)) != VI_OK) return rc;
+        if ((rc = wg_gemm_batched(c, false, N, pR, pVn, pVw, bc)) != VI_OK) return rc;
+        if ((rc = wg_gemm_batched(c, true, N, pVn, pVw, pD2, bc)) != VI_OK) return rc;
         hipLaunchKernelGGL(k_vt_vec_slot, dim3((unsigned)bc), dim3(256), 0, c->stream, N, Vn, d_y, recc, slotc, d_yt);
         VI_HIP(hipGetLastError());
     }

@@ -81,57 +81,9 @@ template <int CPW>
 __global__ __launch_bounds__(64) void k_jacobi_vectors_wave(int N, const double2* __restrict__ rotlog, int64_t log_stride,
                                                             const int* __restrict__ nround_in, double* __restrict__ Vout)
 {
-    const int Np = (N + 3) & ~3, m = Np >> 1, M = Np >> 2;
-    const int lane = threadIdx.x;
     const int64_t sys = blockIdx.y;
-    const int col0 = blockIdx.x * CPW;                  // final slots whose eigenvectors this wave builds
-    const double2* logp = rotlog + sys * log_stride;
-    const int64_t nround = nround_in[sys];
-    WaveReplay W[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int col = col0 + c;
-        W[c].init(lane, M);
-        W[c].x0 = (4 * lane == col) ? 1.0 : 0.0;
-        W[c].x1 = (4 * lane + 1 == col) ? 1.0 : 0.0;
-        W[c].x2 = (4 * lane + 2 == col) ? 1.0 : 0.0;
-        W[c].x3 = (4 * lane + 3 == col) ? 1.0 : 0.0;
-    }
-    constexpr int PF = 4;                               // rounds of (c, s) prefetched per batch
-    const bool has = lane < M;
-    for (int64_t r1 = nround; r1 > 0; r1 -= PF) {
-        const int nb = r1 >= PF ? PF : (int)r1;
-        double2 pf[PF][4];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pf[u][j] = make_double2(1.0, 0.0);
-            if (u < nb && has) {
-                const double2* lp = logp + (r1 - 1 - u) * (int64_t)(4 * M) + lane;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pf[u][j] = lp[j * M];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (u < nb) {
-                const bool intra = ((r1 - 1 - u) % m) == 0;
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) W[c].round(pf[u], intra);
-            }
-    }
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int col = col0 + c;
-        if (col >= N) break;
-        double* Vo = Vout + sys * (int64_t)N * N + (int64_t)col * N;     // eigenvector `col`, indexed by original index
-        if (has) {
-            if (4 * lane < N) Vo[4 * lane] = W[c].x0;
-            if (4 * lane + 1 < N) Vo[4 * lane + 1] = W[c].x1;
-            if (4 * lane + 2 < N) Vo[4 * lane + 2] = W[c].x2;
-            if (4 * lane + 3 < N) Vo[4 * lane + 3] = W[c].x3;
-        }
-    }
+    jacobi_vector_strip<CPW>(N, rotlog + sys * log_stride, nround_in[sys], blockIdx.x * CPW, threadIdx.x,
+                             Vout + sys * (int64_t)N * N);
 }
 
 }  // namespace

@@ -48,7 +48,7 @@ _lib._sig('vi_warm_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.V
 _lib._sig('vi_basis_solve_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, C.c_double, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_max_sweeps', C.c_int)
-_lib._sig('vi_brent_warm_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, C.c_int64, *([_lib.VOIDP] * 14), C.c_double,
+_lib._sig('vi_brent_warm_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, C.c_int64, *([_lib.VOIDP] * 18), C.c_double,
           *([_lib.VOIDP] * 5))
 _lib._sig('vi_exp10_f64', C.c_int, _lib.VOIDP, _lib.VOIDP, C.c_int64)
 _lib._sig('vi_reg_floor_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
@@ -618,15 +618,21 @@ class FitEngine(object):
         self.stats['shared_solves'] = self.stats.get('shared_solves', 0) + nsh
         return out
 
+    DEVICE_BRENT_MIN_RECORDS = 8
+
     def device_brent_enabled(self):
         """Brent's iteration of the whole batch in one launch (vi_brent_warm_f64, csrc/vi_brent.hip) instead of one round of
-        launches per iterate.  OFF unless VINTERP_DEVICE_BRENT=1: the kernel reproduces the host-driven iteration bit for bit
-        (tests/test_gpu_search_stages.py) but keeps every record's rotated system at the middle of its bracket, and without
-        the re-basing next to the root Brent needs 25 iterations per record instead of 15 and every iterate more sweeps:
-        measured on 1000 records 546 ms against 520 in one pipeline, 522 against 446 in four."""
-        if os.environ.get('VINTERP_DEVICE_BRENT', '0') != '1':
+        launches per iterate: a workgroup owns a record from its bracket to its root, re-basing its rotated system as the host
+        path does.  Bit for bit the host-driven iteration (tests/test_gpu_search_stages.py), so a record's answer does not
+        depend on which of the two served it.  From eight records on: a record fitted alone keeps the host-driven rounds
+        (one workgroup would do the products of the re-basing alone that the host path spreads over the chip).
+        VINTERP_DEVICE_BRENT=0 / 1 forces either.  Measured, 1000 records: 543 -> 466 ms in one pipeline, 481 -> 419 in four."""
+        e = os.environ.get('VINTERP_DEVICE_BRENT', 'auto')
+        if e == '0' or not self.warm_enabled() or len(self.regularization_list) != 1:
             return False
-        return self.warm_enabled() and len(self.regularization_list) == 1 and self.T >= 2
+        if len(self._rebase_schedule()) > 4:
+            return False
+        return e == '1' or self.T >= self.DEVICE_BRENT_MIN_RECORDS
 
     def _device_brent(self, recs, brackets, name):
         """Brent's iteration for the records `recs` (brackets: dicts with alpha, alpha0, val, val0, nu) on the device.
@@ -652,8 +658,12 @@ class FitEngine(object):
         dnu = up('nu', [b['nu'] for b in brackets], np.float64)
         droot, dother = self._buf('db_root', (n,)), self._buf('db_other', (n,))
         dit, dfc, dst = (self._buf('db_' + k, (n,), np.int32) for k in ('it', 'fc', 'st'))
-        _lib.check(_lib.lib.vi_brent_warm_f64(h, n, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, self.At.ptr, self.dW.ptr,
-                                              self.db.ptr, drec.ptr, dslot.ptr, dxa.ptr, dxb.ptr, dfa.ptr, dfb.ptr, dnu.ptr,
+        sched = list(self._rebase_schedule()) if os.environ.get('VINTERP_REBASE', '1') != '0' else []
+        rule = np.array([len(sched)] + (sched + [0.] * 4)[:4] + [self.REBASE_AGAIN_AFTER, self.REBASE_AGAIN_WITHIN,
+                        1. if (sched and os.environ.get('VINTERP_REBASE2', '1') != '0') else 0.], dtype=np.float64)
+        _lib.check(_lib.lib.vi_brent_warm_f64(h, n, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, self.dAWA.ptr,
+                                              self.R[name].ptr, self.dy.ptr, rule.ctypes.data_as(_lib.VOIDP), self.At.ptr,
+                                              self.dW.ptr, self.db.ptr, drec.ptr, dslot.ptr, dxa.ptr, dxb.ptr, dfa.ptr, dfb.ptr, dnu.ptr,
                                               EPS, droot.ptr, dother.ptr, dit.ptr, dfc.ptr, dst.ptr), 'vi_brent_warm_f64')
 
         def down(d, dt):
@@ -662,6 +672,8 @@ class FitEngine(object):
             return a
         root, other, its, fcs, sts = down(droot, np.float64), down(dother, np.float64), down(dit, np.int32), \
             down(dfc, np.int32), down(dst, np.int32)
+        self.stats['rebased'] = self.stats.get('rebased', 0) + int((sts >> 8).sum())
+        sts = sts & 0xff
         if np.any(sts == 3):
             raise RuntimeError('Failed to converge after %d iterations.' % alpha_search.MAXITER)
         self.stats['solves'] += int(fcs.sum())
