@@ -429,3 +429,104 @@ def test_doubtful_walk_values_are_asked_for_together():
     clean = AS.run_batched([1000], lambda r, a: np.array([exact_f(x) for x in a]), prefetch=8)
     assert got[0] == clean[0] and got[1] == clean[1]
     assert sum(1 for _, nx in rounds if nx) <= 3, rounds          # doubtful decades in one or two requests + the bracket ends
+
+
+def _random_tables(rng, T, npts):
+    """Exact and plain (noisy) walk tables of T records: sign changes anywhere, NaNs, exact zeros of chi^2 - nu, values inside
+    the sign margin, records that are too smooth at once, plain values that contradict the exact ones."""
+    exact = np.empty((T, 102))
+    for t in range(T):
+        lvl = rng.choice([500., 650., 850., 950., 1050.])
+        tab = lvl + rng.choice([1., 30., 300.]) * rng.standard_normal(102)
+        if t % 3 == 0:
+            tab[rng.integers(1, 102):] -= rng.uniform(100., 600.)
+        if t % 5 == 0:
+            tab[rng.integers(0, 102)] = float('nan')
+        if t % 7 == 0:
+            tab[rng.integers(0, 102)] = npts * rng.choice(AS.SCALE_FACTORS)
+        if t % 11 == 0:
+            tab[rng.integers(0, 102)] = npts * rng.choice(AS.SCALE_FACTORS) * (1. + 3e-4)
+        if t % 13 == 0:
+            tab[0] = rng.uniform(100., 590.)
+        exact[t] = tab
+    noise = 1e-5 * rng.standard_normal((T, 102))
+    big = rng.random((T, 102)) < 0.01                       # a plain value that is plainly wrong now and then
+    noise[big] = 0.2 * rng.standard_normal(int(big.sum()))
+    return exact, exact * (1. + noise)
+
+
+@pytest.mark.parametrize('refine', [False, True])
+@pytest.mark.parametrize('prefetch', [1, 8, 32, 102])
+def test_table_driver_makes_the_coroutines_requests_and_decisions(refine, prefetch):
+    """run_table_batched (the walk of a whole batch on arrays) against run_batched (a coroutine per record): the same requests
+    record by record - plain and exact -, the same outcome, scale factor and bracket for every record, on random noisy tables.
+    Brent's iteration is replaced by a stub (both drivers hand it the same brackets), so NaN ends are covered too."""
+    rng = np.random.default_rng(11 + prefetch)
+    T, npts = 300, 1000
+    exact, plain = _random_tables(rng, T, npts)
+    npl = [npts] * T
+    npl[5] = None
+    npl[17] = 800
+
+    def make():
+        seen = set()
+        handed = {}
+
+        def ev(rec, la, ex=None):
+            ex = np.zeros(len(la), bool) if ex is None else ex
+            out = np.empty(len(la))
+            for j, (r, a, e) in enumerate(zip(rec.tolist(), la.tolist(), ex.tolist())):
+                assert a == math.floor(a)
+                assert (r, a, e) not in seen, 'asked twice'
+                seen.add((r, a, e))
+                out[j] = (exact if e else plain)[r, int(round(-a))]
+            return out
+
+        def solver(ids, brs):
+            for i, b in zip(ids, brs):
+                handed[i] = dict(b)
+            return [(0.5 * (b['alpha'] + b['alpha0']), 3, 2, b['alpha']) for b in brs]
+        return seen, handed, ev, solver
+    s1, h1, ev1, so1 = make()
+    a = AS.run_batched(npl, ev1, prefetch=prefetch, refine=refine, brent_solver=so1)
+    s2, h2, ev2, so2 = make()
+    b = AS.run_table_batched(npl, ev2, prefetch=prefetch, refine=refine, brent_solver=so2)
+    assert s1 == s2, (sorted(s1 - s2)[:5], sorted(s2 - s1)[:5])
+    assert a[1] == b[1]
+    assert a[3] == b[3]
+    assert np.array_equal(np.array(a[0], dtype=float), np.array(b[0], dtype=float), equal_nan=True)
+    for i in range(T):
+        assert a[2][i] == b[2][i] or (repr(a[2][i]) == repr(b[2][i])), (i, a[2][i], b[2][i])
+    assert set(h1) == set(h2)
+    for i in h1:
+        assert repr(h1[i]) == repr(h2[i]), (i, h1[i], h2[i])
+    outc = set(a[1])
+    assert {'root', 'no_root', 'too_smooth', 'skipped'} <= outc
+    if refine:
+        assert any(x.get('walk_redone_exact') for x in a[2])
+
+
+def test_table_driver_with_brents_iteration():
+    """... and with Brent's iteration behind it (BrentBatch on a smooth chi^2 with a noisy walk): the roots of run_batched, bit
+    for bit, with and without a solver that declines some records."""
+    def chi2_true(r, x):
+        return 450. + 300. / (1. + math.exp(-(x + 28.3 + 0.37 * r) * 2.)) + r
+
+    def noisy(rec, la, exact=None):
+        out = []
+        for j, (r, a) in enumerate(zip(rec.tolist(), la.tolist())):
+            e = exact is not None and exact[j]
+            noise = 0. if (e or a != math.floor(a)) else 2e-5 * math.sin(a * 7.3 + r)
+            out.append(chi2_true(r, a) * (1. + noise))
+        return np.array(out)
+    npl = [1000] * 40
+    ref = AS.run_batched(npl, noisy, prefetch=32, refine=True, vector_brent=True)
+    got = AS.run_table_batched(npl, noisy, prefetch=32, refine=True)
+    assert got[0] == ref[0] and got[1] == ref[1] and got[2] == ref[2] and got[3] == ref[3]
+    assert ref[1].count('root') == 40
+
+    def solver(ids, brs):                       # answers every other record, leaves the rest to the driver
+        return [None if i % 2 else (b['alpha'] + 0.25, 4, 3, b['alpha0']) for i, b in zip(ids, brs)]
+    ref = AS.run_batched(npl, noisy, prefetch=32, refine=True, brent_solver=solver)
+    got = AS.run_table_batched(npl, noisy, prefetch=32, refine=True, brent_solver=solver)
+    assert got[0] == ref[0] and got[1] == ref[1] and got[2] == ref[2] and got[3] == ref[3]

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libvinterp.so')
+LIB_PATH = os.environ.get('VINTERP_LIB') or os.path.join(_HERE, 'csrc', 'libvinterp.so')    # VINTERP_LIB: a diagnostic build
 
 
 class VinterpError(RuntimeError):

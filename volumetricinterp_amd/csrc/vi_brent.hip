@@ -32,6 +32,19 @@ bool vi_jacobi_supported(int N);
 double vi_floor_warm();                  // vi_fit.hip: absolute rotation floor of the rotated-system solves
 extern "C" int vi_max_sweeps(void);
 
+#ifdef VI_STAMPS
+// diagnostic build only (-DVI_STAMPS): cycle sums of thread 0 of every workgroup per part of k_brent_warm; vi_debug_brent_stamps
+__device__ unsigned long long g_brent_stamps[16];
+#define BR_STAMP(k)                                                                   \
+    do {                                                                              \
+        const unsigned long long t_ = __builtin_readcyclecounter();                   \
+        if (threadIdx.x == 0) atomicAdd(&g_brent_stamps[k], t_ - stamp_t);            \
+        stamp_t = __builtin_readcyclecounter();                                       \
+    } while (0)
+#else
+#define BR_STAMP(k)
+#endif
+
 namespace {
 
 struct BrentState {
@@ -116,6 +129,43 @@ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rto
     return false;
 }
 
+// Out of line: the solver keeps the register budget it has as a kernel of its own (inlined into the loop below it shares the
+// 168 registers of 12 waves per CU with thirty live pointers and spills in its rounds).
+template <int IT>
+__device__ __noinline__ void jacobi_system_call(unsigned char* lds_raw, int N, const double* Xs, double sc, const double* ys,
+                                                double rcond, double abs_floor, double* Cs, double2* logp, int max_sweeps,
+                                                int* sweeps_s, int* nround_s)
+{
+    jacobi_system<IT>(lds_raw, N, Xs, sc, ys, rcond, abs_floor, Cs, nullptr, logp, max_sweeps, sweeps_s, nullptr, 0, nround_s,
+                      nullptr);
+}
+
+// The move of a record's rotated system (vi_warm_rebase_f64's kernels in its order), out of line for the same reason.
+__device__ __noinline__ void rebase_call(unsigned char* lds_raw, int N, const double2* logp, int64_t nround, double* Vs,
+                                         double* VwS, double* VnS, const double* AWAr, const double* Rm, double* D1s, double* D2s,
+                                         const double* yr, double* yts)
+{
+    const int tid = threadIdx.x, NT = blockDim.x, nw = NT >> 6, lane = tid & 63, wave = tid >> 6;
+    const int NN = N * N;
+    for (int col0 = wave * 4; col0 < N; col0 += nw * 4) jacobi_vector_strip<4>(N, logp, nround, col0, lane, VwS);
+    __syncthreads();
+    double* ldsg = reinterpret_cast<double*>(lds_raw);
+    wg_gemm<false>(N, Vs, VwS, VnS, ldsg);
+    for (int e = tid; e < NN; e += NT) Vs[e] = VnS[e];
+    __syncthreads();
+    wg_gemm<false>(N, AWAr, VnS, VwS, ldsg);
+    wg_gemm<true>(N, VnS, VwS, D1s, ldsg);
+    wg_gemm<false>(N, Rm, VnS, VwS, ldsg);
+    wg_gemm<true>(N, VnS, VwS, D2s, ldsg);
+    for (int k = wave; k < N; k += nw) {                 // k_vt_vec_slot
+        double acc = 0.0;
+        for (int r = lane; r < N; r += 64) acc = fma(VnS[(int64_t)k * N + r], yr[r], acc);
+        for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_down(acc, o2);
+        if (lane == 0) yts[k] = acc;
+    }
+    __syncthreads();
+}
+
 template <int IT>
 __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     int N, int64_t P, int ntask, double* D1, double* D2, double* yt, double* V, const double* __restrict__ AWA,
@@ -147,11 +197,21 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     const int nb = (int)((P + 255) / 256);
     const int lane = tid & 63, wave = tid >> 6;
 
+#ifdef VI_STAMPS
+    unsigned long long stamp_t = __builtin_readcyclecounter();
+    const unsigned long long wall0 = wall_clock64();
+    if (threadIdx.x == 0) atomicMin(&g_brent_stamps[12], wall0);
+#endif
     for (;;) {
         if (tid == 0) shi[0] = atomicAdd(queue, 1);
         __syncthreads();
         const int task = shi[0];
-        if (task >= ntask) break;
+        if (task >= ntask) {
+#ifdef VI_STAMPS
+            if (threadIdx.x == 0) { const unsigned long long w1 = wall_clock64(); atomicAdd(&g_brent_stamps[11], w1 - wall0); atomicMax(&g_brent_stamps[13], w1); }
+#endif
+            break;
+        }
         const int64_t slot = t_slot[task], rec = t_rec[task];
         const double nu = t_nu[task];
         double* D1s = D1 + slot * NN;
@@ -171,6 +231,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             *st = s;
         }
         __syncthreads();
+        BR_STAMP(0);
         while (!st->done) {
             const double alpha = vi_exp10(st->xcur);
             // ---- X = f (D1 + alpha D2), f the power of two that brings max|X| into [1, 2)   (k_form_pair_scaled)
@@ -189,10 +250,14 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             }
             for (int e = tid; e < NN; e += NT) Xs[e] = fma(alpha, D2s[e], D1s[e]) * f;
             __syncthreads();
+            BR_STAMP(1);
             // ---- the truncated solve in the rotated system (the K3 kernel's body)
-            jacobi_system<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, nullptr, logp, max_sweeps, shi + 1,
-                              nullptr, 0, shi + 2, nullptr);
+            jacobi_system_call<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, logp, max_sweeps, shi + 1, shi + 2);
             __syncthreads();
+            BR_STAMP(2);
+#ifdef VI_STAMPS
+            if (tid == 0) { atomicAdd(&g_brent_stamps[8], (unsigned long long)shi[1]); atomicAdd(&g_brent_stamps[9], 1ull); atomicAdd(&g_brent_stamps[10], (unsigned long long)shi[2]); }
+#endif
             // ---- C = V c'   (k_v_vec)
             for (int k = tid; k < N; k += NT) red[k] = cp[k];
             __syncthreads();
@@ -202,6 +267,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                 shC[r] = acc;
             }
             __syncthreads();
+            BR_STAMP(3);
             // ---- chi^2   (k_chi2_part<256, 1>: one fma chain over n per data point, a fixed tree over the 256 points of a
             //      block; k_chi2_sum: the blocks in order).  Two blocks of points at a time, one per half of 512 threads.
             for (int b0 = 0; b0 < nb; b0 += 2) {
@@ -227,6 +293,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                 if (tid < 512 && t == 0 && blk < nb) part[blk] = red[tid];
                 __syncthreads();
             }
+            BR_STAMP(4);
             if (tid == 0) {
                 double chi = 0.0;
                 for (int j = 0; j < nb; ++j) chi += part[j];
@@ -248,29 +315,13 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                 *st = s;
             }
             __syncthreads();
+            BR_STAMP(5);
             if (st->rebase_now && st->status == 0 && !st->done) {
                 // ---- move the rotated system to this iterate's alpha (vi_warm_rebase_f64): eigenvectors Vw of the rotated
                 //      system out of the rotation log of the solve just done, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V,
                 //      yt = V^T y from the untransformed matrices - the host path's kernels, the host path's order
-                const int64_t nround = shi[2];
-                for (int col0 = wave * 4; col0 < N; col0 += nw * 4) jacobi_vector_strip<4>(N, logp, nround, col0, lane, VwS);
-                __syncthreads();
-                double* ldsg = reinterpret_cast<double*>(lds_raw);
-                wg_gemm<false>(N, Vs, VwS, VnS, ldsg);
-                for (int e = tid; e < NN; e += NT) Vs[e] = VnS[e];
-                __syncthreads();
-                wg_gemm<false>(N, AWA + rec * NN, VnS, VwS, ldsg);
-                wg_gemm<true>(N, VnS, VwS, D1s, ldsg);
-                wg_gemm<false>(N, Rm, VnS, VwS, ldsg);
-                wg_gemm<true>(N, VnS, VwS, D2s, ldsg);
-                const double* yr = ysrc + rec * N;
-                for (int k = wave; k < N; k += nw) {                 // k_vt_vec_slot
-                    double acc = 0.0;
-                    for (int r = lane; r < N; r += 64) acc = fma(VnS[(int64_t)k * N + r], yr[r], acc);
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_down(acc, o2);
-                    if (lane == 0) yt[slot * N + k] = acc;
-                }
-                __syncthreads();
+                rebase_call(lds_raw, N, logp, shi[2], Vs, VwS, VnS, AWA + rec * NN, Rm, D1s, D2s, ysrc + rec * N, yt + slot * N);
+                BR_STAMP(7);
             }
             if (tid == 0 && !st->done) {
                 BrentState s = *st;
@@ -305,6 +356,21 @@ void brent_geometry(int N, int& threads, int& it)
 }
 
 }  // namespace
+
+#ifdef VI_STAMPS
+extern "C" int vi_debug_brent_stamps(double* out, int reset)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_brent_stamps), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        h[12] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_brent_stamps), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int vi_exp10_f64(const double* x, double* out, int64_t n)
 {

@@ -840,9 +840,15 @@ class FitEngine(object):
             if self.device_brent_enabled() and not cold and not multisection:
                 def solver(recs, brs, _name=name):
                     return self._device_brent(recs, brs, _name)
-            alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
-                                                                   multisection=multisection, refine=refine,
-                                                                   vector_brent=T >= 16, brent_solver=solver)
+            if not multisection and T >= 16 and os.environ.get('VINTERP_TABLE_WALK', '1') != '0':
+                # the walks of the whole batch on one (records x decades) table: the coroutines' requests and decisions
+                # without the coroutines (110 ms of interpreter per 1000 records, which concurrent pipelines cannot share)
+                alphas, outcomes, info, nev = alpha_search.run_table_batched(npts, evaluate, prefetch=prefetch, refine=refine,
+                                                                             brent_solver=solver)
+            else:
+                alphas, outcomes, info, nev = alpha_search.run_batched(npts, evaluate, prefetch=prefetch,
+                                                                       multisection=multisection, refine=refine,
+                                                                       vector_brent=T >= 16, brent_solver=solver)
             for t in range(T):
                 params[t][name] = alphas[t]
             infos[name] = dict(outcomes=outcomes, info=info, evaluations=nev)
