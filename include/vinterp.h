@@ -243,7 +243,9 @@ int  vi_reg_floor_f64(vi_ctx* ctx, int64_t T, int32_t N, const double* d_AWA, co
  * other decade by decade, so they are solved in the eigenbasis of a reference system of the same decade - d_V / d_D2 as
  * vi_warm_prepare_f64 leaves them for a reference record (mean weights of the batch), one slot per decade.  For B
  * (record, basis slot, alpha) triples: (V^T AWA[rec] V + alpha D2) c' = V^T y[rec] with the truncation rule of
- * vi_solve_trunc_f64, C = V c'.  1-4 Jacobi sweeps per system instead of 8-24. */
+ * vi_solve_trunc_f64, C = V c'.  1-4 Jacobi sweeps per system instead of 8-24.  Its chi^2 only decides the signs of the
+ * walk (the search asks for the bracket ends, and for values near the target, again from cold solves), so the iteration ends
+ * at |a_pq| <= 1e-6 sqrt|a_pp a_qq| (VINTERP_WALK_TOL; csrc/vi_fit.hip walk_tolerance). */
 int  vi_basis_solve_f64(vi_ctx* ctx, int64_t B, int32_t N, const double* d_AWA, const double* d_y,
                         const int32_t* d_rec, const int32_t* d_basis, const double* d_alpha, const double* d_V,
                         const double* d_D2, double rcond, double* d_C, int32_t* d_rank, int32_t* d_sweeps /* may be NULL */);

@@ -34,6 +34,9 @@ eng.fit_resident([P] * T)
 out = (C.c_double * 16)()
 _lib.lib.vi_debug_brent_stamps.argtypes = [C.POINTER(C.c_double), C.c_int]
 _lib.lib.vi_debug_brent_stamps(out, 1)
+hist = (C.c_double * 128)()
+_lib.lib.vi_debug_brent_hist.argtypes = [C.POINTER(C.c_double), C.c_int]
+_lib.lib.vi_debug_brent_hist(hist, 1)
 eng.stats = dict(solves=0, launches=0)
 t0 = time.perf_counter()
 eng.fit_resident([P] * T)
@@ -50,3 +53,7 @@ print('   workgroups busy %.1f %% of the launch (sum of their lifetimes / (256 x
 v = v[:8]
 for n_, c_ in zip(names, v):
     print('   %-36s %14.0f cycles  %5.1f %%' % (n_, c_, 100. * c_ / v.sum()))
+_lib.lib.vi_debug_brent_hist(hist, 0)
+hh = np.array(list(hist)).reshape(64, 2)
+print('   sweeps by iteration (iteration: solves, mean sweeps):')
+print('   ' + '  '.join('%d: %d, %.1f' % (i, hh[i, 1], hh[i, 0] / max(1., hh[i, 1])) for i in range(64) if hh[i, 1] > 0))

@@ -26,3 +26,13 @@ print('info keys', inf['info'][0].keys() if inf['info'][0] else None)
 a=np.array(its); print('brent iterations: mean %.1f max %d; >20: %d; >40: %d'%(a.mean(), a.max(), (a>20).sum(), (a>40).sum()))
 lo=[i.get('bracket',(0,0))[0] for i in inf['info'] if i and 'bracket' in i]
 print('bracket lower ends: ', np.unique(np.array(lo), return_counts=True))
+I = inf['info']
+oc = inf['outcomes']
+print('guard: jump %d, polished_cold %d, redone_cold %d, inconsistent %d of %d roots' % (
+    sum(1 for i in I if i and i.get('jump')), len(inf.get('polished_cold', [])), len(inf.get('redone_cold', [])),
+    sum(1 for i, o in zip(I, oc) if o == 'root' and not i.get('consistent')), oc.count('root')))
+print('polish iterations:', [i.get('polish_iterations') for i in I if i and i.get('polished_cold')])
+os.environ['VINTERP_STAGE_TIMES'] = '1'
+eng.stats = dict(solves=0, launches=0)
+res = eng.fit_resident([P]*T); ctx.sync()
+print({k: round(v, 1) for k, v in eng.stats.items() if k.startswith('ms_')})

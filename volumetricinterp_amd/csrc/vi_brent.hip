@@ -35,6 +35,7 @@ extern "C" int vi_max_sweeps(void);
 #ifdef VI_STAMPS
 // diagnostic build only (-DVI_STAMPS): cycle sums of thread 0 of every workgroup per part of k_brent_warm; vi_debug_brent_stamps
 __device__ unsigned long long g_brent_stamps[16];
+__device__ unsigned long long g_brent_hist[64][2];     // by iteration index: sweeps, solves
 #define BR_STAMP(k)                                                                   \
     do {                                                                              \
         const unsigned long long t_ = __builtin_readcyclecounter();                   \
@@ -195,7 +196,6 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     double* VwS = VwW + (int64_t)blockIdx.x * NN;                          // eigenvectors of a rotated system / product scratch
     double* VnS = VnW + (int64_t)blockIdx.x * NN;                          // the new basis V Vw
     const int nb = (int)((P + 255) / 256);
-    const int lane = tid & 63, wave = tid >> 6;
 
 #ifdef VI_STAMPS
     unsigned long long stamp_t = __builtin_readcyclecounter();
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             __syncthreads();
             BR_STAMP(2);
 #ifdef VI_STAMPS
-            if (tid == 0) { atomicAdd(&g_brent_stamps[8], (unsigned long long)shi[1]); atomicAdd(&g_brent_stamps[9], 1ull); atomicAdd(&g_brent_stamps[10], (unsigned long long)shi[2]); }
+            if (tid == 0) { const int ii_ = st->it < 63 ? st->it : 63; atomicAdd(&g_brent_hist[ii_][0], (unsigned long long)shi[1]); atomicAdd(&g_brent_hist[ii_][1], 1ull); atomicAdd(&g_brent_stamps[8], (unsigned long long)shi[1]); atomicAdd(&g_brent_stamps[9], 1ull); atomicAdd(&g_brent_stamps[10], (unsigned long long)shi[2]); }
 #endif
             // ---- C = V c'   (k_v_vec)
             for (int k = tid; k < N; k += NT) red[k] = cp[k];
@@ -358,6 +358,17 @@ void brent_geometry(int N, int& threads, int& it)
 }  // namespace
 
 #ifdef VI_STAMPS
+extern "C" int vi_debug_brent_hist(double* out, int reset)
+{
+    unsigned long long h[64][2];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_brent_hist), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 64; ++i) { out[2 * i] = (double)h[i][0]; out[2 * i + 1] = (double)h[i][1]; }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_brent_hist), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int vi_debug_brent_stamps(double* out, int reset)
 {
     unsigned long long h[16];

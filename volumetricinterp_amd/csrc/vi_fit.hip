@@ -23,7 +23,8 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps);
 bool vi_jacobi_supported(int N);
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride = 0);
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride = 0,
+                    double conv_tol = 0.0);
 bool vi_jacobi_vectors_supported(int N);
 int vi_jacobi_vectors(vi_ctx* c, int64_t B, int N, const void* d_log, int max_sweeps, const int* d_nround, double* d_V,
                       int64_t log_stride = 0);
@@ -535,14 +536,22 @@ int gemm_groups(vi_ctx* c, rocblas_operation ta, rocblas_operation tb, int m, in
     return VI_OK;
 }
 
-// C[i] = op(A[i]) B[i] for `count` N x N column-major matrices, one workgroup each, by wg_gemm (vi_gemm_device.h): the
-// products of the re-basing, whose bits the device-side search (k_brent_warm) must reproduce.
+// C[i] = op(A[i]) B[i] for `count` N x N column-major matrices by wg_gemm (vi_gemm_device.h): the products of the re-basing,
+// whose bits the device-side search (k_brent_warm) must reproduce.  Few products (a record fitted alone) are cut into
+// blocks of 8 x 8 thread tiles of 3 x 3 elements, one workgroup of 64 threads each: the same elements (a sum does not
+// know its tile), 36 times the CUs at N = 144.
 template <bool TA>
 __global__ __launch_bounds__(640) void k_wg_gemm(int N, const double* const* __restrict__ pA, const double* const* __restrict__ pB,
-                                                 const double* const* __restrict__ pC)
+                                                 const double* const* __restrict__ pC, int bt)
 {
     extern __shared__ __align__(16) double shg[];
-    wg_gemm<TA>(N, pA[blockIdx.x], pB[blockIdx.x], const_cast<double*>(pC[blockIdx.x]), shg);
+    if (bt <= 0) {
+        wg_gemm<TA>(N, pA[blockIdx.x], pB[blockIdx.x], const_cast<double*>(pC[blockIdx.x]), shg);
+    } else {
+        const int nt = (N + 2) / 3, nb = (nt + bt - 1) / bt;
+        const int bi = blockIdx.y % nb, bj = blockIdx.y / nb;
+        wg_gemm<TA, 3>(N, pA[blockIdx.x], pB[blockIdx.x], const_cast<double*>(pC[blockIdx.x]), shg, bi * bt, bt, bj * bt, bt);
+    }
 }
 
 int wg_gemm_batched(vi_ctx* c, bool ta, int N, const double** pA, const double** pB, const double** pC, int64_t count)
@@ -551,12 +560,20 @@ int wg_gemm_batched(vi_ctx* c, bool ta, int N, const double** pA, const double**
     const int nt = (N + 5) / 6;
     int threads = ((nt * nt + 63) / 64) * 64;
     if (threads > 640) threads = 640;
+    int bt = 0;
+    dim3 grid((unsigned)count);
+    if (count * 4 <= c->n_cu && N > 24) {           // the chip is far from full: blocks of 8 x 8 thread tiles of 3 x 3
+        bt = 8;
+        const int nb = ((N + 2) / 3 + bt - 1) / bt;
+        grid = dim3((unsigned)count, (unsigned)(nb * nb));
+        threads = 64;
+    }
     if (ta) {
         VI_HIP(hipFuncSetAttribute((const void*)k_wg_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(k_wg_gemm<true>, dim3((unsigned)count), dim3(threads), shm, c->stream, N, pA, pB, pC);
+        hipLaunchKernelGGL(k_wg_gemm<true>, grid, dim3(threads), shm, c->stream, N, pA, pB, pC, bt);
     } else {
         VI_HIP(hipFuncSetAttribute((const void*)k_wg_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(k_wg_gemm<false>, dim3((unsigned)count), dim3(threads), shm, c->stream, N, pA, pB, pC);
+        hipLaunchKernelGGL(k_wg_gemm<false>, grid, dim3(threads), shm, c->stream, N, pA, pB, pC, bt);
     }
     VI_HIP(hipGetLastError());
     return VI_OK;
@@ -965,6 +982,25 @@ extern "C" size_t vi_rotation_log_bytes(int32_t N) { return log_record_bytes(N);
 extern "C" int vi_max_sweeps(void) { return JACOBI_MAX_SWEEPS; }
 double vi_floor_warm() { return JACOBI_FLOOR_WARM; }
 
+// End of the Jacobi iteration in the solves of the bracket walk (vi_basis_solve_f64), whose chi^2 only decides signs - values
+// within 5e-3 of the target are asked for again from cold solves (alpha_search.WALK_SIGN_MARGIN): every |a_pq| <= 1e-6 x
+// sqrt|a_pp a_qq| instead of eps x.  Measured on 1000 records x 49 decades (tools/exp_walk_floor.py, tools/exp_walk_tol.sh):
+// rotating sweeps per system 2.21 -> 1.59, the walk 141 -> 124 ms, and the deviation of the walk's chi^2 from the cold one
+// unchanged to three digits (max 1.13e-3, 99.9 % 2.94e-4 - it comes from eigenvalues next to the truncation cut, not from
+// the end of the iteration; at 1e-4 the maximum grows to 2.4e-3, at 1e-3 to 1.2e-2).  An off-diagonal element of relative
+// size tol moves an eigenvalue by tol^2 of itself and a coefficient's contribution to the fit by tol of the data norm.
+// VINTERP_WALK_TOL overrides (0 = the criterion of all other solves).
+namespace {
+double walk_tolerance()
+{
+    static const double v = [] {
+        const char* e = getenv("VINTERP_WALK_TOL");
+        return e ? atof(e) : 1e-6;
+    }();
+    return v;
+}
+}  // namespace
+
 extern "C" int vi_decompose_f64(vi_ctx* c, int64_t B, int32_t N, const double* d_AWA, const int32_t* d_rec,
                                 const double* d_alpha0, const double* d_R, const double* d_y, double rcond, double* d_C,
                                 int32_t* d_rank, void* d_log, int32_t* d_nround)
@@ -1160,7 +1196,8 @@ extern "C" int vi_basis_solve_f64(vi_ctx* c, int64_t B, int32_t N, const double*
         form_pair_scaled(c, bc, NN, D1, d_D2, nullptr, d_basis + i0, d_alpha + i0, D1, scl);
         VI_HIP(hipGetLastError());
         rc = vi_jacobi_solve(c, bc, N, D1, scl, yt, nullptr, rcond, cp, d_rank ? d_rank + i0 : nullptr, ws,
-                             JACOBI_MAX_SWEEPS, d_sweeps ? d_sweeps + i0 : nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM);
+                             JACOBI_MAX_SWEEPS, d_sweeps ? d_sweeps + i0 : nullptr, nullptr, 0, nullptr, JACOBI_FLOOR_WARM, 0,
+                             walk_tolerance());
         if (rc != VI_OK) return rc;
         hipLaunchKernelGGL(k_v_vec, dim3((unsigned)bc), dim3(256), (size_t)N * sizeof(double), c->stream, N, d_V,
                            d_basis + i0, cp, d_C + i0 * N);

@@ -53,6 +53,16 @@ __device__ unsigned long long g_jacobi_stamps[16];
 #define VI_STAMP(k)
 #endif
 
+#ifdef VI_ROTHIST
+// diagnostic build only (-DVI_ROTHIST): rotations and solves by sweep index over all k_jacobi_solve launches; vi_debug_rot_hist
+__device__ unsigned long long g_rot_hist[32][2];
+#define VI_ROT_COUNT(sweep, r0, r1, r2, r3)                                                                              \
+    atomicAdd(&g_rot_hist[(sweep) < 31 ? (sweep) : 31][0],                                                               \
+              (unsigned long long)(((r0).y != 0.0) + ((r1).y != 0.0) + ((r2).y != 0.0) + ((r3).y != 0.0)))
+#define VI_ROT_SWEEP(sweep)                                                                                               \
+    do { if (threadIdx.x == 0) atomicAdd(&g_rot_hist[(sweep) < 31 ? (sweep) : 31][1], 1ull); } while (0)
+#endif
+
 #include "vi_jacobi_device.h"
 
 namespace {
@@ -62,14 +72,15 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
     int N, const double* __restrict__ X, const double* __restrict__ scl, const double* __restrict__ y,
     const int* __restrict__ rec, double rcond, double abs_floor, double* __restrict__ C, int* __restrict__ rank,
     double2* __restrict__ rotlog, int64_t log_stride, int max_sweeps, int* __restrict__ sweeps_out,
-    double* __restrict__ lam_out, int lam_raw, int* __restrict__ nround_out, unsigned long long* __restrict__ round_acc)
+    double* __restrict__ lam_out, int lam_raw, int* __restrict__ nround_out, unsigned long long* __restrict__ round_acc,
+    double conv_tol)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int64_t sys = blockIdx.x;
     jacobi_system<IT>(lds_raw, N, X + sys * (int64_t)N * N, scl ? scl[sys] : 1.0, y + (int64_t)(rec ? rec[sys] : sys) * N, rcond,
                       abs_floor, C + sys * N, rank ? rank + sys : nullptr, rotlog + sys * log_stride, max_sweeps,
                       sweeps_out ? sweeps_out + sys : nullptr, lam_out ? lam_out + sys * N : nullptr, lam_raw,
-                      nround_out ? nround_out + sys : nullptr, round_acc);
+                      nround_out ? nround_out + sys : nullptr, round_acc, conv_tol);
 }
 
 // Eigenvectors from the rotation log: V = J_1 J_2 ... J_K, so column k of V is the reverse replay applied to the unit
@@ -97,6 +108,20 @@ extern "C" int vi_debug_jacobi_stamps(double* out, int reset)
     if (reset) {
         memset(h, 0, sizeof(h));
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_jacobi_stamps), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef VI_ROTHIST
+extern "C" int vi_debug_rot_hist(double* out, int reset)
+{
+    unsigned long long h[32][2];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rot_hist), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) { out[2 * i] = (double)h[i][0]; out[2 * i + 1] = (double)h[i][1]; }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rot_hist), h, sizeof(h)) != hipSuccess) return -1;
     }
     return 0;
 }
@@ -152,7 +177,8 @@ size_t vi_jacobi_log_bytes(int N, int max_sweeps) { return (size_t)jacobi_log_st
 template <int IT>
 static int launch_jacobi(vi_ctx* c, int threads, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                          const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride_in)
+                         int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride_in,
+                         double conv_tol)
 {
     const size_t shm = vi_jacobi_lds_bytes(N);
     // per launch, not cached: a context per device may exist in one process and the attribute is per device
@@ -165,7 +191,7 @@ static int launch_jacobi(vi_ctx* c, int threads, int64_t B, int N, const double*
     if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[slot][0], c->stream));
     hipLaunchKernelGGL(k_jacobi_solve<IT>, dim3((unsigned)B), dim3(threads), shm, c->stream, N, d_X, d_scl, d_y, d_rec,
                        rcond, abs_floor, d_C, d_rank, (double2*)d_log, log_stride, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround,
-                       c->solve_timing ? c->d_rounds : nullptr);
+                       c->solve_timing ? c->d_rounds : nullptr, conv_tol);
     VI_HIP(hipGetLastError());
     if (c->solve_timing) {
         VI_HIP(hipEventRecord(c->evs[slot][1], c->stream));
@@ -176,14 +202,15 @@ static int launch_jacobi(vi_ctx* c, int threads, int64_t B, int N, const double*
 }
 
 // d_X: systems scaled by k_scale_system (B x N x N, only read).  log_stride (in 16-byte rotation entries, 0 = the logs
-// lie back to back): distance between the rotation logs of consecutive systems in d_log.
+// lie back to back): distance between the rotation logs of consecutive systems in d_log.  conv_tol > 0: a looser end of the
+// iteration (jacobi_system).
 int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double* d_scl, const double* d_y,
                     const int* d_rec, double rcond, double* d_C, int* d_rank, void* d_log, int max_sweeps,
-                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride)
+                    int* d_sweeps, double* d_lam, int lam_raw, int* d_nround, double abs_floor, int64_t log_stride, double conv_tol)
 {
     int threads, it;
     jacobi_geometry(N, threads, it);
-#define VI_J(IT) return launch_jacobi<IT>(c, threads, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor, log_stride)
+#define VI_J(IT) return launch_jacobi<IT>(c, threads, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor, log_stride, conv_tol)
     if (it <= 1) VI_J(1);
     if (it <= 2) VI_J(2);
     VI_J(3);

@@ -9,6 +9,10 @@
 #ifndef VI_STAMP
 #define VI_STAMP(k)
 #endif
+#ifndef VI_ROT_COUNT
+#define VI_ROT_COUNT(sweep, r0, r1, r2, r3)
+#define VI_ROT_SWEEP(sweep)
+#endif
 
 namespace {
 
@@ -251,7 +255,7 @@ __device__ __forceinline__ void jacobi_system(
     unsigned char* lds_raw, int N, const double* __restrict__ Xs, double sc, const double* __restrict__ ys, double rcond,
     double abs_floor, double* __restrict__ Cs, int* __restrict__ rank_s, double2* __restrict__ logp, int max_sweeps,
     int* __restrict__ sweeps_s, double* __restrict__ lam_s, int lam_raw, int* __restrict__ nround_s,
-    unsigned long long* __restrict__ round_acc)
+    unsigned long long* __restrict__ round_acc, double conv_tol = 0.0)
 {
     const int NT = blockDim.x;
     const int Np = (N + 3) & ~3;          // padded to a multiple of four with inert indices
@@ -318,7 +322,9 @@ __device__ __forceinline__ void jacobi_system(
     // rcond * max|lambda| and max|diag| <= max|lambda|, so this never skips a pair that reaches the cut
     const double drop = rcond * mxd;
     const double eps2 = 2.220446049250313e-16 * 2.220446049250313e-16;
-    const double conv2 = VI_CONV_FACTOR * VI_CONV_FACTOR * eps2;      // termination test, see below
+    // termination test, see below; conv_tol > 0: the iteration ends once every |a_pq| <= conv_tol sqrt|a_pp a_qq| (the solves of
+    // the bracket walk, whose chi^2 only decides signs: vi_basis_solve_f64)
+    const double conv2 = conv_tol > 0.0 ? conv_tol * conv_tol : VI_CONV_FACTOR * VI_CONV_FACTOR * eps2;
     int sweep = 0, ycur = 0;
     bool converged = false;               // false: the sweep cap ended the iteration
     int64_t nround = 0;
@@ -327,6 +333,7 @@ __device__ __forceinline__ void jacobi_system(
 #endif
     for (; sweep < max_sweeps; ++sweep) {
         int rotated = 0;
+        VI_ROT_SWEEP(sweep);
         for (int r = 0; r < m; ++r, ++nround) {
             const bool intra = r == 0;            // round 0 of a sweep: the pairs inside the units, no permutation
             const double2* csc = cs;
@@ -348,6 +355,7 @@ __device__ __forceinline__ void jacobi_system(
                     rot_stage<0, 2, 1, 3>(d, yy, drop, abs_floor, rotated, r0, r1);
                     rot_stage<0, 3, 1, 2>(d, yy, drop, abs_floor, rotated, r2, r3);
                 }
+                VI_ROT_COUNT(sweep, r0, r1, r2, r3);
                 cs[tid] = r0;
                 cs[M + tid] = r1;
                 cs[2 * M + tid] = r2;
