@@ -419,9 +419,12 @@ def run(args):
                    'jacobi_kernel_ms_summed': k3_ms,
                    'jacobi_lds_gbs': lds_b / max(1e-9, busy_ms * 1e-3) / 1e9,
                    'jacobi_lds_frac': lds_b / max(1e-9, busy_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
-                   'jacobi_lds_note': 'algorithmic LDS bytes of all K3 launches over the time K3 was running - the sum of '
-                                      'the launch durations, capped at the wall time of the fit when the launches of '
-                                      'concurrent pipelines overlap',
+                   'jacobi_lds_note': 'algorithmic LDS bytes of all K3 launches - k_jacobi_solve and the Jacobi rounds inside '
+                                      'k_brent_warm (one launch per pipeline: Brent\'s iteration of its records, whose whole '
+                                      'duration is counted, chi^2 and re-basing included) - over the time they were running: '
+                                      'the sum of the launch durations, capped at the wall time of the fit when the launches '
+                                      'of concurrent pipelines overlap; solves = systems of the k_jacobi_solve launches + '
+                                      'records of the k_brent_warm launches',
                    'outcomes': {o_: ocb.count(o_) for o_ in set(ocb)},
                    'redone_cold': len(resb['search']['curvature'].get('redone_cold', [])),
                    'note': 'configs[2]: %d records of the bench geometry fitted as one batch (chi2 search, covariance), '

@@ -135,10 +135,10 @@ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rto
 template <int IT>
 __device__ __noinline__ void jacobi_system_call(unsigned char* lds_raw, int N, const double* Xs, double sc, const double* ys,
                                                 double rcond, double abs_floor, double* Cs, double2* logp, int max_sweeps,
-                                                int* sweeps_s, int* nround_s)
+                                                int* sweeps_s, int* nround_s, unsigned long long* round_acc)
 {
     jacobi_system<IT>(lds_raw, N, Xs, sc, ys, rcond, abs_floor, Cs, nullptr, logp, max_sweeps, sweeps_s, nullptr, 0, nround_s,
-                      nullptr);
+                      round_acc);
 }
 
 // The move of a record's rotated system (vi_warm_rebase_f64's kernels in its order), out of line for the same reason.
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     const double* __restrict__ t_nu, double rcond, double abs_floor, int max_sweeps, double xtol, double rtol, int maxiter,
     int* __restrict__ queue, double* __restrict__ Xw, double2* __restrict__ logw, int64_t log_stride, double* __restrict__ cw,
     double* __restrict__ o_root, double* __restrict__ o_other, int* __restrict__ o_iters, int* __restrict__ o_funcalls,
-    int* __restrict__ o_status, size_t lds_jacobi)
+    int* __restrict__ o_status, size_t lds_jacobi, unsigned long long* __restrict__ round_acc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // behind the Jacobi kernel's LDS image: coefficients, chi^2 reduction, state
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             __syncthreads();
             BR_STAMP(1);
             // ---- the truncated solve in the rotated system (the K3 kernel's body)
-            jacobi_system_call<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, logp, max_sweeps, shi + 1, shi + 2);
+            jacobi_system_call<IT>(lds_raw, N, Xs, 1.0 / f, yt + slot * N, rcond, abs_floor, cp, logp, max_sweeps, shi + 1, shi + 2,
+                                   round_acc);
             __syncthreads();
             BR_STAMP(2);
 #ifdef VI_STAMPS
@@ -445,12 +446,21 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
         hipLaunchKernelGGL(k_brent_warm<ITV>, dim3((unsigned)nwg), dim3(threads), shm, c->stream, N, P, (int)ntask, d_D1, d_D2, \
                            d_yt, d_V, d_AWA, d_R, d_y, rr, VwW, VnW, d_At, d_W, d_b, d_rec, d_slot, d_xa, d_xb, d_fa, d_fb, d_nu, rcond, abs_floor,          \
                            (int)max_sweeps, 2e-12, 4 * 2.220446049250313e-16, 100, queue, Xw, logw,                           \
-                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj_eff);  \
+                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj_eff, \
+                           c->solve_timing ? c->d_rounds : nullptr);                                                        \
     } while (0)
+    // (vi_solve_timing: the launch counts among the eigen-solve launches - it is one, record after record)
+    const int tslot = (int)(c->solve_launches % vi_ctx::NSOLVE_EV);
+    if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[tslot][0], c->stream));
     if (it <= 1) VI_B(1);
     else if (it <= 2) VI_B(2);
     else VI_B(3);
 #undef VI_B
     VI_HIP(hipGetLastError());
+    if (c->solve_timing) {
+        VI_HIP(hipEventRecord(c->evs[tslot][1], c->stream));
+        c->solve_launches += 1;
+        c->solve_systems += ntask;
+    }
     return VI_OK;
 }
