@@ -136,6 +136,17 @@ int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const dou
 int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon,
                  const double* d_alt, int64_t T, const double* d_C,
                  const double* d_hull_eq, int32_t F, double hull_tol, double* d_out);
+/* Many timesteps on ONE grid (BASELINE configs[3]: a GPU's share of 10 000 timesteps, all on the same 256^3 grid - Estimate.__call__
+ * (estimate.py:110-123) once per timestep in the reference, which rebuilds the basis of the grid every time): the basis matrix
+ * of the grid is assembled once and kept in HBM, and every batch of timesteps is one matrix product.
+ *   vi_eval_basis_f64     d_Y[n*Q + q] = basis_n(q), N x Q doubles (19 GB at N = 144 on 256^3); with hull_eq != NULL the
+ *                         entries of a point that fails the hull test (as in vi_eval_f64) are NaN
+ *   vi_eval_resident_f64  out[t*Q + q] = sum_n d_Y[n*Q + q] * C[t*N + n]  - NaN outside the hull through the NaN of d_Y,
+ *                         NaN for a timestep whose coefficients are NaN (a failed fit), as vi_eval_f64 gives them.
+ * Agrees with vi_eval_f64 to rounding (the sum over n is taken in the library's order; tests/test_gpu_eval_resident.py). */
+int  vi_eval_basis_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                       const double* d_hull_eq, int32_t F, double hull_tol, double* d_Y);
+int  vi_eval_resident_f64(vi_model* model, int64_t Q, int64_t T, const double* d_Y, const double* d_C, double* d_out);
 /* Arithmetic of the Legendre degree recurrences inside vi_eval_f64 for this model: 0 = fp64 (default; the reference
  * computes in float64 throughout, sphharmlag.py:118-145), 1 = fp32 chains with everything else in fp64 - the variant
  * BASELINE configs[4] sweeps against the 1e-6 tolerance.  Orders with an fp32 kernel: (MAXL, MAXK) = (6,4), (2,8), (12,8);

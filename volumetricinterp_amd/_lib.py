@@ -87,6 +87,8 @@ _sig('vi_eval_grad_f64', C.c_int, VOIDP, I64, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP)
 _sig('vi_eval_err_f64', C.c_int, VOIDP, I64, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP)
 _sig('vi_transform_f64', C.c_int, VOIDP, I64, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP)
 _sig('vi_eval_f64', C.c_int, VOIDP, I64, VOIDP, VOIDP, VOIDP, I64, VOIDP, VOIDP, C.c_int32, C.c_double, VOIDP)
+_sig('vi_eval_basis_f64', C.c_int, VOIDP, I64, VOIDP, VOIDP, VOIDP, VOIDP, C.c_int32, C.c_double, VOIDP)
+_sig('vi_eval_resident_f64', C.c_int, VOIDP, I64, I64, VOIDP, VOIDP, VOIDP)
 _sig('vi_eval_f64_host', C.c_int, VOIDP, I64, c_double_p, c_double_p, c_double_p, I64, c_double_p, c_double_p,
      C.c_int32, C.c_double, c_double_p)
 
@@ -102,7 +104,7 @@ _sig('vi_rccl_init', C.c_int, VOIDP, C.c_int, C.c_int, C.c_char_p)
 _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
-EXPORTS = ['vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
+EXPORTS = ['vi_eval_basis_f64', 'vi_eval_resident_f64', 'vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
            'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_mem_info', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']

@@ -932,6 +932,83 @@ extern "C" int vi_transform_f64(vi_model* m, int64_t P, const double* d_lat, con
     return VI_OK;
 }
 
+// ---- evaluation of many timesteps on one grid from a RESIDENT basis (BASELINE configs[3]: a GPU's share of 10 000 timesteps on
+// one 256^3 grid).  vi_eval_f64 recomputes the basis of a point for every tile of 32 timesteps - right for one timestep or a
+// few, and it keeps the matrix cores waiting for the recurrences half of the time.  With hundreds of
+// timesteps on the same grid the basis matrix is worth keeping: N x Q doubles - 19 GB at the default order on 256^3, a
+// fifteenth of this GPU's HBM - assembled once by K1 (vi_basis_f64, basis-major so that every access is a contiguous run of
+// points), the rows of points outside the hull set to NaN, so that the mask costs nothing afterwards: NaN times anything is
+// NaN.  The evaluation is then a plain product out(Q x T) = Y(Q x N) C(N x T) - the library's GEMM, in tiles of 128 timesteps
+// (tools/microbench/dgemm_eval_shape.hip: 59 TFLOP/s at 128, 32 at 64, 56 at 256; Y is read once per tile: 0.15 B/flop).
+namespace {
+__global__ void k_mask_basis(int64_t Q, int N, const unsigned char* __restrict__ mask, double* __restrict__ Y)
+{
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= Q || mask[q] != 0) return;
+    const double nan = __builtin_nan("");
+    for (int n = 0; n < N; ++n) Y[(int64_t)n * Q + q] = nan;
+}
+}  // namespace
+
+extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
+                                 const double* d_hull_eq, int32_t F, double hull_tol, double* d_Y)
+{
+    VI_REQUIRE(m && d_lat && d_lon && d_alt && d_Y, "null argument");
+    VI_REQUIRE(Q >= 0 && F >= 0, "negative size");
+    VI_REQUIRE(F == 0 || d_hull_eq, "hull facet count given without facet equations");
+    if (Q == 0) return VI_OK;
+    int rc = vi_basis_f64(m, Q, d_lat, d_lon, d_alt, d_Y, 1, Q);
+    if (rc != VI_OK || F == 0) return rc;
+    const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + (size_t)F * sizeof(float4) + 64;
+    if (need > m->hull_bytes) {
+        VI_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (m->d_hull) VI_HIP(hipFree(m->d_hull));
+        m->d_hull = nullptr;
+        m->hull_bytes = 0;
+        VI_HIP(hipMalloc((void**)&m->d_hull, need));
+        m->hull_bytes = need;
+    }
+    hipLaunchKernelGGL(k_prep_hull, dim3(4), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
+    VI_HIP(hipGetLastError());
+    if ((size_t)Q > m->mask_bytes) {
+        VI_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (m->d_mask) VI_HIP(hipFree(m->d_mask));
+        m->d_mask = nullptr;
+        m->mask_bytes = 0;
+        VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
+        m->mask_bytes = (size_t)Q;
+    }
+    hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
+                       d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
+    hipLaunchKernelGGL(k_mask_basis, dim3(nblocks(Q, 256)), dim3(256), 0, m->ctx->stream, Q, m->N, m->d_mask, d_Y);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+}
+
+extern "C" int vi_eval_resident_f64(vi_model* m, int64_t Q, int64_t T, const double* d_Y, const double* d_C, double* d_out)
+{
+    VI_REQUIRE(m && d_Y && d_C && d_out, "null argument");
+    VI_REQUIRE(Q >= 0 && T >= 0, "negative size");
+    if (Q == 0 || T == 0) return VI_OK;
+    vi_ctx* c = m->ctx;
+    VI_HIP(hipSetDevice(c->device));
+    const int N = m->N;
+    const double one = 1.0, zero = 0.0;
+    const int64_t TT = 128;                          // timesteps per product
+    const int64_t QQ = (int64_t)1 << 30;             // points per product (the library's dimensions are 32-bit)
+    EvalTimer timer(c);
+    for (int64_t t0 = 0; t0 < T; t0 += TT) {
+        const int64_t tc = (T - t0) < TT ? (T - t0) : TT;
+        for (int64_t q0 = 0; q0 < Q; q0 += QQ) {
+            const int64_t qc = (Q - q0) < QQ ? (Q - q0) : QQ;
+            // column-major: out(qc x tc, ld Q) = Y(qc x N, ld Q) * C(N x tc, ld N)
+            VI_ROCBLAS(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (rocblas_int)qc, (rocblas_int)tc, N,
+                                     &one, d_Y + q0, (rocblas_int)Q, d_C + t0 * N, N, &zero, d_out + t0 * Q + q0, (rocblas_int)Q));
+        }
+    }
+    return VI_OK;
+}
+
 extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
                            int64_t T, const double* d_C, const double* d_hull_eq, int32_t F, double hull_tol,
                            double* d_out)

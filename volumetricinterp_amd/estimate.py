@@ -116,6 +116,13 @@ class Estimate(object):
                                              out.ctypes.data_as(P)), 'vi_eval_f64_host')
         return out
 
+    def resident_grid(self, gdlat, gdlon, gdalt, check_hull=True):
+        """The points of a grid that MANY timesteps are going to be evaluated on (the reference calls Estimate.__call__ once
+        per timestep and rebuilds the basis of the grid every time, estimate.py:110-115): their basis matrix is assembled once
+        and stays in device memory (N x Q doubles - 19 GB at the default order on a 256^3 grid), and every batch of timesteps
+        is one matrix product (ResidentGrid.evaluate_coeffs / ResidentGrid.__call__).  Same values as __call__ to rounding."""
+        return ResidentGrid(self, gdlat, gdlon, gdalt, check_hull)
+
     def gradient(self, time, gdlat, gdlon, gdalt, check_hull=True):
         """Gradient of the fitted parameter at the points: array of shape gdlat.shape + (3,), components along the
         model coordinates z, theta, phi exactly as ``Model.grad_basis`` defines them (sphharmlag.py:148-184), NaN outside
@@ -198,3 +205,77 @@ class Estimate(object):
         except IndexError:
             raise ValueError('Requested time out of range of data file.')
         return C, dC
+
+
+class ResidentGrid(object):
+    """Basis matrix of a fixed set of points, resident on the device (Estimate.resident_grid)."""
+
+    def __init__(self, est, gdlat, gdlon, gdalt, check_hull=True):
+        self.est = est
+        self.shape = np.asarray(gdlat).shape
+        lat = np.ascontiguousarray(np.asarray(gdlat, dtype=np.float64).ravel())
+        lon = np.ascontiguousarray(np.asarray(gdlon, dtype=np.float64).ravel())
+        alt = np.ascontiguousarray(np.asarray(gdalt, dtype=np.float64).ravel())
+        if not (lat.size == lon.size == alt.size):
+            raise ValueError('gdlat, gdlon, gdalt must have the same shape')
+        self.Q = lat.size
+        ctx = est.model.ctx
+        N = est.model.nbasis
+        free, _ = ctx.mem_info()
+        if self.Q * N * 8 > 0.9 * free:
+            raise MemoryError('basis matrix of %d points x %d functions (%.1f GB) does not fit the device (%.1f GB free)'
+                              % (self.Q, N, self.Q * N * 8 / 1e9, free / 1e9))
+        self.dY = ctx.empty((N, self.Q))
+        if self.Q == 0:
+            return
+        d = [ctx.to_device(a) for a in (lat, lon, alt)]
+        if check_hull:
+            eq, tol = est._hull()
+            dh, F = ctx.to_device(eq), eq.shape[0]
+        else:
+            dh, F, tol = None, 0, 0.
+        _lib.check(_lib.lib.vi_eval_basis_f64(est.model.handle(), self.Q, d[0].ptr, d[1].ptr, d[2].ptr,
+                                              dh.ptr if dh is not None else None, F, tol, self.dY.ptr), 'vi_eval_basis_f64')
+        ctx.sync()
+        for a in d:
+            a.free()
+        if dh is not None:
+            dh.free()
+
+    def evaluate_coeffs(self, C, out=None):
+        """out[t] = density of coefficient row C[t] on the grid; (T, Q) host array."""
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        N = self.est.model.nbasis
+        if C.ndim != 2 or C.shape[1] != N:
+            raise ValueError('coefficients must have shape (T, %d)' % N)
+        T = C.shape[0]
+        if out is None:
+            out = np.empty((T, self.Q), dtype=np.float64)
+        elif out.shape != (T, self.Q) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous float64 array of shape (%d, %d)' % (T, self.Q))
+        if T == 0 or self.Q == 0:
+            return out
+        ctx = self.est.model.ctx
+        # timesteps in slabs whose output fits a quarter of the free device memory
+        free, _ = ctx.mem_info()
+        slab = int(max(1, min(T, (free // 4) // max(1, self.Q * 8))))
+        dC = ctx.to_device(C)
+        dO = ctx.empty((slab, self.Q))
+        for t0 in range(0, T, slab):
+            tc = min(slab, T - t0)
+            _lib.check(_lib.lib.vi_eval_resident_f64(self.est.model.handle(), self.Q, tc, self.dY.ptr, dC.offset_ptr(t0 * N),
+                                                     dO.ptr), 'vi_eval_resident_f64')
+            _lib.check(_lib.lib.vi_d2h(ctx.handle, out[t0:t0 + tc].ctypes.data_as(_lib.VOIDP), dO.ptr, tc * self.Q * 8), 'd2h')
+        dC.free()
+        dO.free()
+        return out
+
+    def __call__(self, times):
+        """Densities at the grid for a list of datetimes (Estimate.get_C per time): array (len(times),) + grid shape."""
+        C = np.array([np.asarray(self.est.get_C(t)[0], dtype=np.float64) for t in times])
+        return self.evaluate_coeffs(C).reshape((len(times),) + tuple(self.shape))
+
+    def close(self):
+        if self.dY is not None:
+            self.dY.free()
+            self.dY = None
