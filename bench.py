@@ -547,7 +547,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     lo, hi = shard_bounds(Ttot, rank, world)
     share = hi - lo
     resident = os.environ.get('VINTERP_C3_EVAL', 'resident') != 'fused'
-    TILE = min(128 if resident else 64, max(1, share))
+    TILE = min(256 if resident else 64, max(1, share))
     value, error = synth.synth_records(A, share, seed0=1000 + lo) if share else (np.zeros((0, P)), np.ones((0, P)))
     eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
     eng.upload_records(error**-2., value)
@@ -576,7 +576,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
                 _lib.check(_lib.lib.vi_eval_basis_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, dhull.ptr, F, hull_tol, dY.ptr),
                            'vi_eval_basis_f64')
                 bms = ctx.timer_stop_ms()
-                # ... then one matrix product per 128 timesteps
+                # ... then one matrix product (K2r) per call of up to 256 timesteps
                 ctx.timer_start()
                 _lib.check(_lib.lib.vi_eval_resident_f64(h, Q, TILE, dY.ptr, dC.ptr, dout.ptr), 'vi_eval_resident_f64')
                 ems = ctx.timer_stop_ms()
@@ -618,7 +618,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
         'config': {'workload': 'configs[3]: %d timesteps (26-beam x 100-range records, N=144, curvature, chi2 search, '
                                'covariance) sharded ceil(T/N) per rank, no data-path collective; each rank fits its shard as '
                                'one batch and evaluates it on a 256^3 geodetic grid with the hull mask (%s), fp64'
-                               % (Ttot, 'basis matrix of the grid resident in HBM, one matrix product per 128 timesteps'
+                               % (Ttot, 'basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call'
                                   if resident else 'fused matrix-core kernel, basis recomputed per 32 timesteps'),
                    'timesteps': Ttot, 'timesteps_per_rank': -(-Ttot // world), 'grid_points': Q,
                    'evaluation': 'MEASURED on a tile of %d timesteps per rank inside the timed region and SCALED to the '
@@ -628,14 +628,14 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
         'points_per_sec': Ttot * Q / step_s,
         'per_rank_step_s': per_rank, 'per_rank_fit_s': fits,
         'rank0': {'fit_s': float(np.mean(fit_s)) if fit_s else None, 'eval_tile_ms': float(np.mean(tile_ms)) if tile_ms else None,
-                  'eval_tile_timesteps': TILE, 'eval_mode': 'resident basis + dgemm' if resident else 'fused kernel',
+                  'eval_tile_timesteps': TILE, 'eval_mode': 'resident basis + K2r' if resident else 'fused kernel',
                   'eval_basis_ms_once': float(np.mean(basis_ms)) if basis_ms else None,
                   'eval_basis_bytes': int(N) * int(Q) * 8 if resident else 0,
                   'eval_point_timesteps_per_sec': (TILE * Q / (float(np.mean(tile_ms)) * 1e-3)) if tile_ms else None,
                   'records_per_sec_fit': share / float(np.mean(fit_s)) if fit_s else None,
                   'outcomes': {o_: outcomes.count(o_) for o_ in set(outcomes)} if outcomes else None,
                   'pipelines': eng.stats.get('pipelines', 1)},
-        'roofline': {'kernel': ('library dgemm Q x 128 x N on the resident basis' if resident else 'k_eval_sph_mfma')
+        'roofline': {'kernel': ('k_eval_resident (K2r: v_mfma_f64_16x16x4 on the resident basis)' if resident else 'k_eval_sph_mfma')
                                + ' (evaluation tile; the fit side is the k_jacobi_solve line of workload c1)',
                      'bound': 'mfma', 'achieved': (2. * N * TILE * Q / (float(np.mean(tile_ms)) * 1e-3) / 1e12) if tile_ms else None,
                      'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',

@@ -41,13 +41,14 @@ def test_resident_grid_vs_reference(tag):
     g1.close()
 
 
-def test_resident_grid_many_timesteps_vs_oracle_and_fused_kernel():
-    """300 timesteps (two full products of 128 and a rest of 44) on 1777 random points, some outside the hull, one timestep
-    with NaN coefficients (a failed fit): the oracle's A @ C to 1e-10, the fused kernel's values to 1e-12, its NaNs exactly."""
+@pytest.mark.parametrize('Q', [1777, 2052, 8192 + 256])
+def test_resident_grid_many_timesteps_vs_oracle_and_fused_kernel(Q):
+    """300 timesteps (four full tiles of 64 and a rest of 44) on random points, some outside the hull, one timestep with NaN
+    coefficients (a failed fit): the oracle's A @ C to 1e-10, the fused kernel's values to 1e-12, its NaNs exactly.
+    Q = 1777 (odd) goes through the library's product, the others through K2r - 2052 with a ragged last group of points."""
     import oracle
     f, es = _estimate('k8l2')
     rng = np.random.default_rng(18)
-    Q = 1777
     lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
     base = np.concatenate([f['Coeffs'], f['Coeffs'][:2] * 0.5])          # (6, 32)
     C = np.concatenate([base * s for s in rng.uniform(-2., 2., 50)])     # (300, 32)
@@ -71,3 +72,29 @@ def test_resident_grid_many_timesteps_vs_oracle_and_fused_kernel():
     g.close()
     empty = es.resident_grid(lat[:0], lon[:0], alt[:0])
     assert empty.evaluate_coeffs(C[:3]).shape == (3, 0)
+
+
+def test_resident_default_order_both_paths(monkeypatch):
+    """Default order (N = 144, 36 k-steps) on 4096 points x 70 timesteps: K2r against the library's product of the same basis
+    (1e-13) and against the fused kernel (1e-12)."""
+    f, es = _estimate('default')
+    rng = np.random.default_rng(5)
+    Q = 4096
+    lat, lon, alt = rng.uniform(75, 81, Q), rng.uniform(250, 274, Q), rng.uniform(100e3, 700e3, Q)
+    C = np.concatenate([f['Coeffs'] * s for s in rng.uniform(-2., 2., 35)])[:70]
+    assert C.shape == (70, 144)
+    g = es.resident_grid(lat, lon, alt, check_hull=True)
+    own = g.evaluate_coeffs(C)
+    fused = es.evaluate_coeffs(C, lat, lon, alt, check_hull=True)
+    from volumetricinterp_amd import _lib
+    ctx = es.model.ctx
+    dC, dO = ctx.to_device(C), ctx.empty((70, Q + 1))
+    # the library path: the same call with an output whose rows are not 32-byte aligned
+    _lib.check(_lib.lib.vi_eval_resident_f64(es.model.handle(), Q, 70, g.dY.ptr, dC.ptr, dO.offset_ptr(1)), 'vi_eval_resident_f64')
+    lib = dO.download().ravel()[1:1 + 70 * Q].reshape(70, Q)
+    assert np.array_equal(np.isnan(own), np.isnan(fused)) and np.array_equal(np.isnan(own), np.isnan(lib))
+    ok = np.isfinite(fused)
+    assert 0 < ok[0].sum() < Q
+    assert rel(own[ok], lib[ok]) <= 1e-13
+    assert rel(own[ok], fused[ok]) <= 1e-12
+    g.close()

@@ -764,6 +764,7 @@ int vi_eval_sph_mfma(vi_model* m, int64_t Q, const double* lat, const double* lo
                      const double* Cp, const unsigned char* hull, int F, double* out, int64_t* done);
 int vi_eval_sph_split(vi_model* m, int64_t Q, const double* lat, const double* lon, const double* alt, int64_t T,
                       const double* Cp, const unsigned char* hull, int F, double* out, int* handled);
+int vi_eval_resident_mfma(vi_ctx* c, int N, int64_t Q, int64_t T, const double* d_Y, const double* d_C, double* d_out, int* handled);
 namespace {
 
 bool use_fast_eval()
@@ -993,6 +994,13 @@ extern "C" int vi_eval_resident_f64(vi_model* m, int64_t Q, int64_t T, const dou
     vi_ctx* c = m->ctx;
     VI_HIP(hipSetDevice(c->device));
     const int N = m->N;
+    {
+        EvalTimer timer(c);
+        int handled = 0;
+        const int rc = vi_eval_resident_mfma(c, N, Q, T, d_Y, d_C, d_out, &handled);      // K2r (vi_eval_resident.hip)
+        if (rc != VI_OK || handled) return rc;
+    }
+    // shapes outside K2r's (Q not a multiple of 4, orders whose coefficient tile exceeds the LDS): the library's product
     const double one = 1.0, zero = 0.0;
     const int64_t TT = 128;                          // timesteps per product
     const int64_t QQ = (int64_t)1 << 30;             // points per product (the library's dimensions are 32-bit)
