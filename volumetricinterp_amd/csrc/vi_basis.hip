@@ -294,80 +294,111 @@ struct EvalSink {
 constexpr float HULL_BAND = 4.0f;
 constexpr float HULL_BAND_REL = 1.0e-6f;
 
-constexpr int HULL_PP = 4;          // points per thread: every facet read from LDS serves four points
+constexpr int HULL_PP = 8;          // points per thread: every facet fetched serves eight points
+constexpr int HULL_PAD = 16;        // the fp32 facet list is padded to a multiple of 16 with repeats of facet 0
 
-__global__ __launch_bounds__(BLOCK) void k_hull_mask(int64_t Q, const double* __restrict__ lat,
+// Round 3: the facets come through wave-uniform (scalar) loads - four planes per s_load_dwordx16, used as SGPR operands
+// of the packed FMAs - instead of LDS broadcasts: at 4 points per thread the pass issued one ds_read_b128 per facet and
+// thread, 8 LDS clocks for every 46 VALU clocks of a SIMD with four SIMDs on one LDS pipe (~70 % busy), plus a v_mov
+// per facet; eight points per thread halve what is left per point (early-exit test, plane set-up).
+__global__ __launch_bounds__(BLOCK, 4) void k_hull_mask(int64_t Q, const double* __restrict__ lat,
                                                      const double* __restrict__ lon, const double* __restrict__ alt,
                                                      const double* __restrict__ hull, int F, double tol,
                                                      unsigned char* __restrict__ mask)
 {
-    extern __shared__ __align__(16) float4 shpl[];
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const float4* __restrict__ pl = reinterpret_cast<const float4*>(hull + 4 + 4 * (size_t)F);
-    for (int f = threadIdx.x; f < F; f += BLOCK) shpl[f] = pl[f];
-    __syncthreads();
+    const int Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
     const int64_t q0 = (int64_t)blockIdx.x * (BLOCK * HULL_PP) + threadIdx.x;      // points q0 + u * BLOCK
-    double X[HULL_PP], Y[HULL_PP], Z[HULL_PP];
-    float dx[HULL_PP], dy[HULL_PP], dz[HULL_PP], dmax[HULL_PP];
-#pragma unroll
+    const double c0x = hull[0], c0y = hull[1], c0z = hull[2];
+    // geodetic -> ECEF one point after the other (one copy of the fp64 trigonometry, few registers), the fp32 offsets
+    // from c0 handed to the facet loop's registers through LDS (each thread reads back what it wrote: no barrier)
+    __shared__ float sh_d[HULL_PP][3][BLOCK];
+#pragma unroll 1
     for (int u = 0; u < HULL_PP; ++u) {
         const int64_t q = q0 + (int64_t)u * BLOCK;
         const int64_t qc = q < Q ? q : Q - 1;
-        geodetic2ecef(lat[qc], lon[qc], alt[qc], X[u], Y[u], Z[u]);
-        dx[u] = (float)(X[u] - hull[0]);
-        dy[u] = (float)(Y[u] - hull[1]);
-        dz[u] = (float)(Z[u] - hull[2]);
-        dmax[u] = -3.0e38f;
+        double X, Y, Z;
+        geodetic2ecef(lat[qc], lon[qc], alt[qc], X, Y, Z);
+        sh_d[u][0][threadIdx.x] = (float)(X - c0x);
+        sh_d[u][1][threadIdx.x] = (float)(Y - c0y);
+        sh_d[u][2][threadIdx.x] = (float)(Z - c0z);
     }
-    float band[HULL_PP];
-#pragma unroll
-    for (int u = 0; u < HULL_PP; ++u)
-        band[u] = HULL_BAND + HULL_BAND_REL * sqrtf(dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
-    // two points per packed fp32 FMA (v_pk_fma_f32): the pass is VALU-bound (~2/3 of the scalar fp32 issue rate before)
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 px[HULL_PP / 2], py[HULL_PP / 2], pz[HULL_PP / 2];
-#pragma unroll
-    for (int h = 0; h < HULL_PP / 2; ++h) {
-        px[h] = f2{dx[2 * h], dx[2 * h + 1]};
-        py[h] = f2{dy[2 * h], dy[2 * h + 1]};
-        pz[h] = f2{dz[2 * h], dz[2 * h + 1]};
-    }
-    auto facet = [&](const float4 p) {
-#pragma unroll
-        for (int h = 0; h < HULL_PP / 2; ++h) {
-            const f2 d = __builtin_elementwise_fma(f2{p.x, p.x}, px[h],
-                                                   __builtin_elementwise_fma(f2{p.y, p.y}, py[h],
-                                                                             __builtin_elementwise_fma(f2{p.z, p.z}, pz[h], f2{p.w, p.w})));
-            dmax[2 * h] = fmaxf(dmax[2 * h], d.x);
-            dmax[2 * h + 1] = fmaxf(dmax[2 * h + 1], d.y);
-        }
-    };
-    int f = 0;
-    for (; f + 8 <= F; f += 8) {
-#pragma unroll
-        for (int v = 0; v < 8; ++v) facet(shpl[f + v]);
-        // a point is outside as soon as ONE facet says so: leave when every point of the wave is decided
-        bool done = true;
-#pragma unroll
-        for (int u = 0; u < HULL_PP; ++u) done = done && dmax[u] > (float)tol + band[u];
-        if (__all(done)) break;
-    }
-    if (f + 8 > F)
-        for (; f < F; ++f) facet(shpl[f]);
+    f2 px[HULL_PP / 2], py[HULL_PP / 2], pz[HULL_PP / 2], dmax[HULL_PP / 2], thr[HULL_PP / 2];
+    bool finite[HULL_PP];
 #pragma unroll
     for (int u = 0; u < HULL_PP; ++u) {
-        bool in;
-        if (!(fabsf(dx[u]) + fabsf(dy[u]) + fabsf(dz[u]) < 3.0e38f)) in = false;      // NaN / inf coordinates
-        else if (dmax[u] > (float)tol + band[u]) in = false;
-        else if (dmax[u] < (float)tol - band[u]) in = true;
-        else {                                                           // borderline: exact fp64 test
-            const double* __restrict__ eq = hull + 4;
-            in = true;
-            for (int g = 0; g < F; ++g) {
-                const double d = fma(eq[4 * g], X[u], fma(eq[4 * g + 1], Y[u], fma(eq[4 * g + 2], Z[u], eq[4 * g + 3])));
-                in = in && (d <= tol);
+        const float dx = sh_d[u][0][threadIdx.x], dy = sh_d[u][1][threadIdx.x], dz = sh_d[u][2][threadIdx.x];
+        finite[u] = fabsf(dx) + fabsf(dy) + fabsf(dz) < 3.0e38f;                   // false for NaN / inf coordinates
+        px[u / 2][u % 2] = dx;
+        py[u / 2][u % 2] = dy;
+        pz[u / 2][u % 2] = dz;
+        dmax[u / 2][u % 2] = -3.0e38f;
+        thr[u / 2][u % 2] = HULL_BAND + HULL_BAND_REL * sqrtf(dx * dx + dy * dy + dz * dz);       // the band of the point
+    }
+    auto dist = [&](const float4 p, int h) {
+        return __builtin_elementwise_fma(f2{p.x, p.x}, px[h],
+                                         __builtin_elementwise_fma(f2{p.y, p.y}, py[h],
+                                                                   __builtin_elementwise_fma(f2{p.z, p.z}, pz[h], f2{p.w, p.w})));
+    };
+    // four facets per round, the next four fetched while these are applied (the list carries one spare group)
+    float4 n0 = pl[0], n1 = pl[1], n2 = pl[2], n3 = pl[3];
+#pragma unroll 1
+    for (int f = 0; f < Fp; f += 4) {
+        const float4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
+        n0 = pl[f + 4]; n1 = pl[f + 5]; n2 = pl[f + 6]; n3 = pl[f + 7];
+#pragma unroll
+        for (int h = 0; h < HULL_PP / 2; ++h) {
+            const f2 d0 = dist(p0, h), d1 = dist(p1, h), d2 = dist(p2, h), d3 = dist(p3, h);
+            dmax[h].x = fmaxf(fmaxf(dmax[h].x, d0.x), d1.x);
+            dmax[h].y = fmaxf(fmaxf(dmax[h].y, d0.y), d1.y);
+            dmax[h].x = fmaxf(fmaxf(dmax[h].x, d2.x), d3.x);
+            dmax[h].y = fmaxf(fmaxf(dmax[h].y, d2.y), d3.y);
+        }
+        if ((f & (HULL_PAD - 4)) == HULL_PAD - 4) {
+            // a point is outside as soon as ONE facet says so: leave when every point of the wave is decided
+            float slack = 3.0e38f;
+#pragma unroll
+            for (int h = 0; h < HULL_PP / 2; ++h)
+                slack = fminf(slack, fminf(dmax[h].x - thr[h].x, dmax[h].y - thr[h].y));
+            if (__all(slack > (float)tol)) break;
+        }
+    }
+    unsigned inbits = 0, border = 0;
+#pragma unroll
+    for (int u = 0; u < HULL_PP; ++u) {
+        const float dm = dmax[u / 2][u % 2], bd = thr[u / 2][u % 2];
+        if (!finite[u] || dm > (float)tol + bd) continue;                // outside
+        if (dm < (float)tol - bd) inbits |= 1u << u;                      // inside
+        else border |= 1u << u;                                           // within the band of the surface
+    }
+    // Points within the band: the exact fp64 test, one point at a time with the facets spread over the 64 lanes of the wave
+    // (a lane running all F facets alone - F dependent scalar loads - held its whole wave for longer than the fp32 pass of
+    // the entire grid takes: 150 us measured against 95 us with every point deep inside the hull)
+    const int lane = threadIdx.x & 63;
+    const double* __restrict__ eq = hull + 4;
+#pragma unroll 1
+    for (int u = 0; u < HULL_PP; ++u) {
+        const int64_t q = q0 + (int64_t)u * BLOCK;
+        const bool bl = ((border >> u) & 1u) && q < Q;
+        bool in = (inbits >> u) & 1u;
+        unsigned long long todo = __ballot(bl);
+        if (todo) {
+            double X = 0.0, Y = 0.0, Z = 0.0;
+            if (bl) geodetic2ecef(lat[q], lon[q], alt[q], X, Y, Z);
+            while (todo) {
+                const int src = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const double xs = __shfl(X, src), ys = __shfl(Y, src), zs = __shfl(Z, src);
+                bool viol = false;
+                for (int g = lane; g < F; g += 64) {
+                    const double d = fma(eq[4 * g], xs, fma(eq[4 * g + 1], ys, fma(eq[4 * g + 2], zs, eq[4 * g + 3])));
+                    viol = viol || !(d <= tol);
+                }
+                const bool any = __any(viol);
+                if (lane == src) in = !any;
             }
         }
-        const int64_t q = q0 + (int64_t)u * BLOCK;
         if (q < Q) mask[q] = in ? 1 : 0;
     }
 }
@@ -385,6 +416,10 @@ __global__ void k_prep_hull(int F, const double* __restrict__ eq, double* __rest
         hullbuf[4 + 4 * f] = nx; hullbuf[4 + 4 * f + 1] = ny; hullbuf[4 + 4 * f + 2] = nz; hullbuf[4 + 4 * f + 3] = off;
         pl[f] = make_float4((float)nx, (float)ny, (float)nz, (float)(nx * c0x + ny * c0y + nz * c0z + off));
     }
+    // padding of the fp32 list (k_hull_mask reads it in groups of HULL_PAD): facet 0 again - the maximum does not change
+    const int Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
+    for (int f = F + blockIdx.x * blockDim.x + threadIdx.x; f < Fp + 4; f += gridDim.x * blockDim.x)      // + the spare group
+        pl[f] = make_float4((float)eq[0], (float)eq[1], (float)eq[2], (float)(eq[0] * c0x + eq[1] * c0y + eq[2] * c0z + eq[3]));
 }
 
 template <int LCAP, int KCAP, int TT>
@@ -960,7 +995,7 @@ extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, co
     if (Q == 0) return VI_OK;
     int rc = vi_basis_f64(m, Q, d_lat, d_lon, d_alt, d_Y, 1, Q);
     if (rc != VI_OK || F == 0) return rc;
-    const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + (size_t)F * sizeof(float4) + 64;
+    const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + ((size_t)F + HULL_PAD + 4) * sizeof(float4) + 64;
     if (need > m->hull_bytes) {
         VI_HIP(hipStreamSynchronize(m->ctx->stream));
         if (m->d_hull) VI_HIP(hipFree(m->d_hull));
@@ -979,7 +1014,7 @@ extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, co
         VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
         m->mask_bytes = (size_t)Q;
     }
-    hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
+    hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), 0, m->ctx->stream, Q,
                        d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
     hipLaunchKernelGGL(k_mask_basis, dim3(nblocks(Q, 256)), dim3(256), 0, m->ctx->stream, Q, m->N, m->d_mask, d_Y);
     VI_HIP(hipGetLastError());
@@ -1028,7 +1063,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
     VI_HIP(hipSetDevice(m->ctx->device));
     const int N = m->N;
     if (F > 0) {
-        const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + (size_t)F * sizeof(float4) + 64;
+        const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + ((size_t)F + HULL_PAD + 4) * sizeof(float4) + 64;
         if (need > m->hull_bytes) {
             VI_HIP(hipStreamSynchronize(m->ctx->stream));
             if (m->d_hull) VI_HIP(hipFree(m->d_hull));
@@ -1047,7 +1082,7 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
             VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
             m->mask_bytes = (size_t)Q;
         }
-        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), (size_t)F * sizeof(float4), m->ctx->stream, Q,
+        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), 0, m->ctx->stream, Q,
                            d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
         VI_HIP(hipGetLastError());
     }
