@@ -537,8 +537,8 @@ def finish(comm, world):
 
 def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     """Workload c3 (BASELINE configs[3]): T timesteps sharded ceil(T / world) per rank, fitted as one batch per rank (chi^2
-    search, covariance), evaluated on a 256^3 grid by the matrix-core kernel.  The fit of the whole shard is inside the
-    timed region; the evaluation is measured there on a tile of TILE of the rank's timesteps and scaled to the shard."""
+    search, covariance), and EVERY timestep of the shard evaluated on a 256^3 grid by the matrix-core kernel, TILE timesteps
+    per call into one tile buffer - fit and evaluation of the whole shard inside the timed region, nothing scaled."""
     from volumetricinterp_amd import _lib, synth
     from volumetricinterp_amd.fitengine import FitEngine
     from volumetricinterp_amd.parallel import shard_bounds
@@ -557,10 +557,10 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     dq = [ctx.to_device(a.ravel()) for a in g]
     dhull = ctx.to_device(hull_eq)
     F = hull_eq.shape[0]
-    dC = ctx.empty((TILE, N))
-    dout = ctx.empty((TILE, Q))
+    dC = ctx.empty((max(1, share), N))
+    dout = ctx.empty((TILE, Q))                            # one tile of densities, overwritten tile after tile (the consumer's buffer)
     dY = ctx.empty((N, Q)) if resident else None           # the basis matrix of the grid: 19 GB of the GPU's 288
-    fit_s, tile_ms, basis_ms, outcomes = [], [], [], None
+    fit_s, eval_ms, basis_ms, step_s_list, outcomes = [], [], [], [], None
 
     def step(record=False):
         nonlocal outcomes
@@ -569,27 +569,32 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
         t1 = time.perf_counter()
         ems = bms = 0.
         if share:
-            dC.upload(np.nan_to_num(res['Coeffs'][:TILE]))
+            dC.upload(np.nan_to_num(res['Coeffs']))
             if resident:
-                # once per job: the basis of the grid (K1) with the hull mask folded in as NaN rows ...
+                # once per pass: the basis of the grid (K1) with the hull mask folded in as NaN rows ...
                 ctx.timer_start()
                 _lib.check(_lib.lib.vi_eval_basis_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, dhull.ptr, F, hull_tol, dY.ptr),
                            'vi_eval_basis_f64')
                 bms = ctx.timer_stop_ms()
-                # ... then one matrix product (K2r) per call of up to 256 timesteps
-                ctx.timer_start()
-                _lib.check(_lib.lib.vi_eval_resident_f64(h, Q, TILE, dY.ptr, dC.ptr, dout.ptr), 'vi_eval_resident_f64')
-                ems = ctx.timer_stop_ms()
-            else:
-                ctx.timer_start()
-                _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, TILE, dC.ptr, dhull.ptr, F, hull_tol,
-                                                dout.ptr), 'vi_eval_f64')
-                ems = ctx.timer_stop_ms()
+            # ... then EVERY timestep of the shard on the grid, TILE timesteps per call (K2r: one matrix product per call)
+            ctx.timer_start()
+            for s0 in range(0, share, TILE):
+                tl = min(TILE, share - s0)
+                if resident:
+                    _lib.check(_lib.lib.vi_eval_resident_f64(h, Q, tl, dY.ptr, dC.offset_ptr(s0 * N), dout.ptr),
+                               'vi_eval_resident_f64')
+                else:
+                    _lib.check(_lib.lib.vi_eval_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, tl, dC.offset_ptr(s0 * N), dhull.ptr, F,
+                                                    hull_tol, dout.ptr), 'vi_eval_f64')
+            ems = ctx.timer_stop_ms()
             outcomes = res['search']['curvature']['outcomes']
+        ctx.sync()
+        t2 = time.perf_counter()
         if record:
             fit_s.append(t1 - t0)
-            tile_ms.append(ems)
+            eval_ms.append(ems)
             basis_ms.append(bms)
+            step_s_list.append(t2 - t0)
 
     for _ in range(args.warmup):
         step()
@@ -601,14 +606,12 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     ctx.sync()
     comm.barrier()
     wall = comm.max_over_ranks(time.perf_counter() - t0)
-    # per rank: the time a step takes with the evaluation of the whole shard = fit (measured) + basis of the grid (measured,
-    # once) + tile (measured) x share / TILE
-    mine = (float(np.mean(fit_s)) + float(np.mean(basis_ms)) * 1e-3
-            + float(np.mean(tile_ms)) * 1e-3 * (share / max(1, TILE))) if share else 0.
+    # per rank: the measured time of a step - fit of the shard + basis of the grid + evaluation of every timestep of the shard
+    mine = float(np.mean(step_s_list)) if share else 0.
     per_rank = [float(np.frombuffer(b_, dtype=np.float64)[0]) for b_ in comm.allgather_bytes(np.array([mine]).tobytes())]
     fits = [float(np.frombuffer(b_, dtype=np.float64)[0])
             for b_ in comm.allgather_bytes(np.array([float(np.mean(fit_s)) if fit_s else 0.]).tobytes())]
-    step_s = max(per_rank)
+    step_s = wall / args.steps            # barrier to barrier, max over ranks: nothing scaled
     if rank != 0:
         return None
     return {
@@ -621,25 +624,24 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
                                % (Ttot, 'basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call'
                                   if resident else 'fused matrix-core kernel, basis recomputed per 32 timesteps'),
                    'timesteps': Ttot, 'timesteps_per_rank': -(-Ttot // world), 'grid_points': Q,
-                   'evaluation': 'MEASURED on a tile of %d timesteps per rank inside the timed region and SCALED to the '
-                                 'rank\'s shard (a full pass is ~150 s per rank at 8 GPUs); the fit of the whole shard is '
-                                 'measured in full' % TILE},
-        'ms_per_step_measured_wall': wall / args.steps * 1e3,
+                   'evaluation': 'every timestep of the shard is evaluated on the grid inside the timed region, %d timesteps per '
+                                 'call into one tile buffer of densities (nothing scaled or skipped); value = timesteps / '
+                                 '(barrier-to-barrier wall time per step, max over ranks)' % TILE},
         'points_per_sec': Ttot * Q / step_s,
         'per_rank_step_s': per_rank, 'per_rank_fit_s': fits,
-        'rank0': {'fit_s': float(np.mean(fit_s)) if fit_s else None, 'eval_tile_ms': float(np.mean(tile_ms)) if tile_ms else None,
-                  'eval_tile_timesteps': TILE, 'eval_mode': 'resident basis + K2r' if resident else 'fused kernel',
+        'rank0': {'fit_s': float(np.mean(fit_s)) if fit_s else None, 'eval_ms': float(np.mean(eval_ms)) if eval_ms else None,
+                  'eval_timesteps_per_call': TILE, 'eval_mode': 'resident basis + K2r' if resident else 'fused kernel',
                   'eval_basis_ms_once': float(np.mean(basis_ms)) if basis_ms else None,
                   'eval_basis_bytes': int(N) * int(Q) * 8 if resident else 0,
-                  'eval_point_timesteps_per_sec': (TILE * Q / (float(np.mean(tile_ms)) * 1e-3)) if tile_ms else None,
+                  'eval_point_timesteps_per_sec': (share * Q / (float(np.mean(eval_ms)) * 1e-3)) if eval_ms and share else None,
                   'records_per_sec_fit': share / float(np.mean(fit_s)) if fit_s else None,
                   'outcomes': {o_: outcomes.count(o_) for o_ in set(outcomes)} if outcomes else None,
                   'pipelines': eng.stats.get('pipelines', 1)},
         'roofline': {'kernel': ('k_eval_resident (K2r: v_mfma_f64_16x16x4 on the resident basis)' if resident else 'k_eval_sph_mfma')
                                + ' (evaluation tile; the fit side is the k_jacobi_solve line of workload c1)',
-                     'bound': 'mfma', 'achieved': (2. * N * TILE * Q / (float(np.mean(tile_ms)) * 1e-3) / 1e12) if tile_ms else None,
+                     'bound': 'mfma', 'achieved': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12) if eval_ms and share else None,
                      'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',
-                     'frac': (2. * N * TILE * Q / (float(np.mean(tile_ms)) * 1e-3) / 1e12 / FP64_PEAK_TF) if tile_ms else None,
+                     'frac': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12 / FP64_PEAK_TF) if eval_ms and share else None,
                      'traffic': None},
         'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
     }
