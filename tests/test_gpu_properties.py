@@ -68,6 +68,56 @@ def test_hull_mask_is_independent_of_the_coefficients():
     assert np.all(mask == mask[0])
 
 
+def test_hull_mask_pass_on_surface_points_ragged_sizes_and_nonfinite_coordinates():
+    """The mask pass (k_hull_mask: fp32 half-space prefilter with scalar-loaded planes, exact fp64 test of the points within
+    the band of the surface spread over the lanes of a wave) against the definition in NumPy fp64 -
+    inside <=> max_f (n_f . x + d_f) <= tol (estimate.py:153-178) - on points chosen to sit ON the hull (its own vertices,
+    which the fp32 pass cannot decide), next to it (geodetic blends of neighbouring vertices), on query sizes that are not
+    multiples of the 2048 points of a workgroup, and on non-finite coordinates (outside)."""
+    from scipy.spatial import ConvexHull
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.estimate import Estimate, hull_equations
+    from volumetricinterp_amd.geodesy import geodetic2ecef
+    lat, lon, alt = synth.beams(*synth.GEOM_C2, seed=0)
+    R = np.array(geodetic2ecef(lat, lon, alt)).T
+    vid = ConvexHull(R).vertices
+    hv = R[vid]
+    eq, tol = hull_equations(hv)
+    es = Estimate.from_arrays(np.zeros((1, 144)), None, synth.unix_times(1), hv, CFG)
+    rng = np.random.default_rng(5)
+    # blends of pairs of hull vertices in geodetic coordinates: a few metres to kilometres off the surface, both sides
+    i, j = rng.integers(0, len(vid), 3000), rng.integers(0, len(vid), 3000)
+    w = rng.random(3000)
+    bl = [w * a[vid][i] + (1 - w) * a[vid][j] for a in (lat, lon, alt)]
+    g = synth.query_grid(16)
+    qlat = np.concatenate([lat, bl[0], g[0].ravel()])
+    qlon = np.concatenate([lon, bl[1], g[1].ravel()])
+    qalt = np.concatenate([alt, bl[2], g[2].ravel()])
+    X = np.array(geodetic2ecef(qlat, qlon, qalt)).T
+    d = (X @ eq[:, :3].T + eq[:, 3]).max(axis=1)
+    expect = d <= tol
+    decided = np.abs(d - tol) > 1e-6                # the device's ECEF differs from NumPy's in the last bits (~1e-9 m)
+    assert (~decided).sum() < 400 and 200 < expect.sum() < len(expect) - 200
+    for Q in (len(qlat), 1, 63, 2049, 5000):
+        got = es.check_hull(qlat[:Q], qlon[:Q], qalt[:Q])
+        assert np.array_equal(got[decided[:Q]], expect[:Q][decided[:Q]]), Q
+    # the hull's own vertices are inside (Qhull's coplanar points, estimate.py:174-176) - all of them in the fp64 band
+    on = es.check_hull(lat[vid], lon[vid], alt[vid])
+    dv = (hv @ eq[:, :3].T + eq[:, 3]).max(axis=1)
+    assert np.all(on[dv <= tol - 1e-9]) and on.mean() > 0.9
+    # non-finite coordinates: outside, and they do not disturb their neighbours in the wave
+    bad = qlat[:300].copy(), qlon[:300].copy(), qalt[:300].copy()
+    bad[0][5] = np.nan
+    bad[1][70] = np.inf
+    bad[2][131] = -np.inf
+    got = es.check_hull(*bad)
+    ref = es.check_hull(qlat[:300], qlon[:300], qalt[:300])
+    assert not got[5] and not got[70] and not got[131]
+    keep = np.ones(300, dtype=bool)
+    keep[[5, 70, 131]] = False
+    assert np.array_equal(got[keep], ref[keep])
+
+
 def test_record_fit_is_independent_of_its_batch(tmp_path):
     """Records carry no state into each other (interpolate.py:511): fitting a record alone or inside a batch of
     others gives the same coefficients (screened, well-conditioned model; 1e-9 covers the different GEMM shapes)."""

@@ -144,12 +144,17 @@ __device__ __noinline__ void jacobi_system_call(unsigned char* lds_raw, int N, c
 // The move of a record's rotated system (vi_warm_rebase_f64's kernels in its order), out of line for the same reason.
 __device__ __noinline__ void rebase_call(unsigned char* lds_raw, int N, const double2* logp, int64_t nround, double* Vs,
                                          double* VwS, double* VnS, const double* AWAr, const double* Rm, double* D1s, double* D2s,
-                                         const double* yr, double* yts)
+                                         const double* yr, double* yts
+#ifdef VI_STAMPS
+                                         , unsigned long long& stamp_t
+#endif
+                                         )
 {
     const int tid = threadIdx.x, NT = blockDim.x, nw = NT >> 6, lane = tid & 63, wave = tid >> 6;
     const int NN = N * N;
     for (int col0 = wave * 4; col0 < N; col0 += nw * 4) jacobi_vector_strip<4>(N, logp, nround, col0, lane, VwS);
     __syncthreads();
+    BR_STAMP(6);
     double* ldsg = reinterpret_cast<double*>(lds_raw);
     wg_gemm<false>(N, Vs, VwS, VnS, ldsg);
     for (int e = tid; e < NN; e += NT) Vs[e] = VnS[e];
@@ -321,7 +326,11 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                 // ---- move the rotated system to this iterate's alpha (vi_warm_rebase_f64): eigenvectors Vw of the rotated
                 //      system out of the rotation log of the solve just done, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V,
                 //      yt = V^T y from the untransformed matrices - the host path's kernels, the host path's order
-                rebase_call(lds_raw, N, logp, shi[2], Vs, VwS, VnS, AWA + rec * NN, Rm, D1s, D2s, ysrc + rec * N, yt + slot * N);
+                rebase_call(lds_raw, N, logp, shi[2], Vs, VwS, VnS, AWA + rec * NN, Rm, D1s, D2s, ysrc + rec * N, yt + slot * N
+#ifdef VI_STAMPS
+                            , stamp_t
+#endif
+                            );
                 BR_STAMP(7);
             }
             if (tid == 0 && !st->done) {
