@@ -95,6 +95,12 @@ int  vi_dfree(vi_ctx* ctx, void* d_ptr);
 int  vi_h2d(vi_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* synchronous */
 int  vi_d2h(vi_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
 int  vi_dmemset(vi_ctx* ctx, void* d_ptr, int value, size_t bytes);
+/* A download that does not hold the context's stream (the reference has no counterpart: its covariances, interpolate.py:466,
+ * are host arrays already).  vi_d2h_side_mark: after the launches that produce the data, from the launching thread.
+ * vi_d2h_side: blocking, from any host thread - copies on a second stream once the marked work has finished, while the
+ * context's stream runs on.  The source must stay untouched until vi_d2h_side returns. */
+int  vi_d2h_side_mark(vi_ctx* ctx);
+int  vi_d2h_side(vi_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
 /* HIP-event timing on the context's stream (bench.py measures kernels on the stream they run on) */
 /* free / total memory of the context's device (hipMemGetInfo) */

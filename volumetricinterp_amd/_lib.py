@@ -76,6 +76,8 @@ _sig('vi_dfree', C.c_int, VOIDP, VOIDP)
 _sig('vi_h2d', C.c_int, VOIDP, VOIDP, VOIDP, C.c_size_t)
 _sig('vi_d2h', C.c_int, VOIDP, VOIDP, VOIDP, C.c_size_t)
 _sig('vi_dmemset', C.c_int, VOIDP, VOIDP, C.c_int, C.c_size_t)
+_sig('vi_d2h_side_mark', C.c_int, VOIDP)
+_sig('vi_d2h_side', C.c_int, VOIDP, VOIDP, VOIDP, C.c_size_t)
 _sig('vi_mem_info', C.c_int, VOIDP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig('vi_timer_start', C.c_int, VOIDP)
 _sig('vi_timer_stop_ms', C.c_int, VOIDP, c_double_p)
@@ -105,7 +107,7 @@ _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
 EXPORTS = ['vi_eval_basis_f64', 'vi_eval_resident_f64', 'vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
-           'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_dmemset', 'vi_mem_info', 'vi_timer_start', 'vi_timer_stop_ms',
+           'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_d2h_side_mark', 'vi_d2h_side', 'vi_dmemset', 'vi_mem_info', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']
 

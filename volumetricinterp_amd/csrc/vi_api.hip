@@ -72,6 +72,8 @@ extern "C" void vi_ctx_destroy(vi_ctx* c)
         for (int j = 0; j < 2; ++j)
             if (c->evs[i][j]) (void)hipEventDestroy(c->evs[i][j]);
     if (c->d_rounds) (void)hipFree(c->d_rounds);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -144,6 +146,32 @@ extern "C" int vi_d2h(vi_ctx* c, void* h_dst, const void* d_src, size_t bytes)
     VI_HIP(hipSetDevice(c->device));
     VI_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     VI_HIP(hipStreamSynchronize(c->stream));
+    return VI_OK;
+}
+
+// A download beside the stream.  vi_d2h_side_mark (caller's thread, after the launches that produce the data): an event on the
+// context's stream.  vi_d2h_side (any host thread, blocking): a second stream waits for that event, copies, and is drained -
+// the context's stream meanwhile runs what is queued after the mark (FitEngine: the covariances of a batch, 166 MB per 1000
+// records, come down while the consistency guard's solves run; the source buffer must stay untouched until the call returns).
+extern "C" int vi_d2h_side_mark(vi_ctx* c)
+{
+    VI_REQUIRE(c, "null context");
+    VI_HIP(hipSetDevice(c->device));
+    if (!c->side) VI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    if (!c->ev_side) VI_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    VI_HIP(hipEventRecord(c->ev_side, c->stream));
+    return VI_OK;
+}
+
+extern "C" int vi_d2h_side(vi_ctx* c, void* h_dst, const void* d_src, size_t bytes)
+{
+    VI_REQUIRE(c && (bytes == 0 || (h_dst && d_src)), "null argument");
+    VI_REQUIRE(c->side && c->ev_side, "vi_d2h_side without vi_d2h_side_mark");
+    if (!bytes) return VI_OK;
+    VI_HIP(hipSetDevice(c->device));
+    VI_HIP(hipStreamWaitEvent(c->side, c->ev_side, 0));
+    VI_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->side));
+    VI_HIP(hipStreamSynchronize(c->side));
     return VI_OK;
 }
 

@@ -57,6 +57,9 @@ struct vi_ctx {
     long long solve_launches = 0;      // launches recorded since the last reset
     long long solve_systems = 0;       // systems in those launches
     unsigned long long* d_rounds = nullptr;   // device counter: Jacobi rounds (LDS passes) of the recorded launches
+    // downloads that do not hold the stream (vi_d2h_side_mark / vi_d2h_side): a second stream and the event it waits for
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side = nullptr;
 };
 
 int vi_ctx_workspace(vi_ctx* ctx, size_t bytes, void** out);

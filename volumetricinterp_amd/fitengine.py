@@ -24,6 +24,7 @@ Device-side engine behind ``Interpolate.calc_coeffs`` / ``eval_C`` /
 import ctypes as C
 import math
 import os
+import threading
 
 import numpy as np
 
@@ -898,26 +899,56 @@ class FitEngine(object):
             infos[name] = dict(outcomes=outcomes)
         return params, infos
 
-    def finalize(self, params, calccov=True, only=None, out=None):
+    def finalize(self, params, calccov=True, only=None, out=None, compact=False, defer_cov=False):
         """Final eval_C(calccov=True) + chi^2 for every record (interpolate.py:566-569).
 
         Records whose parameters contain NaN become NaN rows (interpolate.py:558-563); with `only`, so do the
-        records not listed."""
+        records not listed.  compact: arrays with one row per solved record only, and the list of those records as a fifth
+        result (the guard re-finalises a handful of records of a batch: no batch-sized arrays for them).
+        The result arrays are written once: rows of solved records by the download itself (straight into the rows when the
+        chunk's records are consecutive - 166 MB of covariances per 1000 records used to pass through a staging array and
+        a row-by-row copy after a NaN fill of the whole array), NaN only into the rows of the others.
+        defer_cov: the covariances stay on the device (a buffer of their own) and come down beside the stream in a host
+        thread (vi_d2h_side) while the caller goes on launching - self._cov_pending is that thread, to be joined (join_cov)
+        before the covariance array is read or written."""
         T, N = self.T, self.N
-        if out is not None:                     # caller's arrays (a pipeline's share of the batch's result)
-            Coeffs, Cov, chi, ranks = out
-            Coeffs[:] = np.nan
-            chi[:] = np.nan
-            ranks[:] = -1
-            if Cov is not None:
-                Cov[:] = np.nan
-        else:
-            Coeffs = np.full((T, N), np.nan)
-            Cov = np.full((T, N, N), np.nan) if calccov else None
-            chi = np.full(T, np.nan)
-            ranks = np.full(T, -1, dtype=np.int32)
+        self._cov_pending = None
         good = [t for t in range(T) if (only is None or t in only)
                 and not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
+        if compact:
+            R = len(good)
+            Coeffs, Cov = np.empty((R, N)), (np.empty((R, N, N)) if calccov else None)
+            chi, ranks = np.empty(R), np.empty(R, dtype=np.int32)
+            rows = np.arange(R, dtype=np.int64)
+        else:
+            if out is not None:                     # caller's arrays (a pipeline's share of the batch's result)
+                Coeffs, Cov, chi, ranks = out
+            else:
+                Coeffs = np.empty((T, N))
+                Cov = np.empty((T, N, N)) if calccov else None
+                chi = np.empty(T)
+                ranks = np.empty(T, dtype=np.int32)
+            rows = np.asarray(good, dtype=np.int64)
+            miss = np.ones(T, dtype=bool)
+            miss[rows] = False
+            if miss.any():
+                Coeffs[miss] = np.nan
+                chi[miss] = np.nan
+                ranks[miss] = -1
+                if Cov is not None:
+                    Cov[miss] = np.nan
+        h = self.ctx.handle
+
+        def down(dst, dev, r0, B, shape, dtype):
+            """B rows of `dev` into dst[rows[r0 : r0 + B]]"""
+            rr = rows[r0:r0 + B]
+            if B and int(rr[-1] - rr[0]) == B - 1 and dst.flags['C_CONTIGUOUS']:
+                view = dst[int(rr[0]):int(rr[0]) + B]                  # consecutive rows: the download lands in place
+                _lib.check(_lib.lib.vi_d2h(h, view.ctypes.data_as(_lib.VOIDP), dev.ptr, view.nbytes), 'd2h')
+            else:
+                tmp = np.empty((B,) + shape, dtype=dtype)
+                _lib.check(_lib.lib.vi_d2h(h, tmp.ctypes.data_as(_lib.VOIDP), dev.ptr, tmp.nbytes), 'd2h')
+                dst[rr] = tmp
         step = max(1, min(len(good), 2048))
         for s in range(0, len(good), step):
             idx = np.asarray(good[s:s + step], dtype=np.int32)
@@ -925,29 +956,59 @@ class FitEngine(object):
             al = {n: np.array([params[t][n] for t in idx], dtype=np.float64) for n in self.regularization_list}
             drec, dC, dH, drank = self._solve_chunk(idx, al, calccov, 'f_')
             dchi = self._buf('f_chi2', (B,))
-            _lib.check(_lib.lib.vi_chi2_f64(self.ctx.handle, B, self.P, N, self.At.ptr, dC.ptr, drec.ptr, self.dW.ptr,
+            _lib.check(_lib.lib.vi_chi2_f64(h, B, self.P, N, self.At.ptr, dC.ptr, drec.ptr, self.dW.ptr,
                                             self.db.ptr, dchi.ptr), 'vi_chi2_f64')
-            Cb = np.empty((B, N))
-            cb = np.empty(B)
-            rb = np.empty(B, dtype=np.int32)
-            h = self.ctx.handle
-            _lib.check(_lib.lib.vi_d2h(h, Cb.ctypes.data_as(_lib.VOIDP), dC.ptr, Cb.nbytes), 'd2h')
-            _lib.check(_lib.lib.vi_d2h(h, cb.ctypes.data_as(_lib.VOIDP), dchi.ptr, cb.nbytes), 'd2h')
-            _lib.check(_lib.lib.vi_d2h(h, rb.ctypes.data_as(_lib.VOIDP), drank.ptr, rb.nbytes), 'd2h')
-            Coeffs[idx] = Cb
-            chi[idx] = cb
-            ranks[idx] = rb
+            down(Coeffs, dC, s, B, (N,), np.float64)
+            down(chi, dchi, s, B, (), np.float64)
+            down(ranks, drank, s, B, (), np.int32)
             if calccov:
                 # dC = H AWA H needs AWA of the selected records, contiguous
                 dsel = self._buf('f_AWAsel', (B, N, N))
                 _lib.check(_lib.lib.vi_form_system_f64(h, B, N, self.dAWA.ptr, drec.ptr, None, None, dsel.ptr),
                            'vi_form_system_f64')
-                ddC = self._buf('f_dC', (B, N, N))
-                _lib.check(_lib.lib.vi_cov_f64(h, B, N, dH.ptr, dsel.ptr, ddC.ptr), 'vi_cov_f64')
-                Db = np.empty((B, N, N))
-                _lib.check(_lib.lib.vi_d2h(h, Db.ctypes.data_as(_lib.VOIDP), ddC.ptr, Db.nbytes), 'd2h')
-                Cov[idx] = Db
+                if defer_cov and not compact:
+                    dall = self._buf('fd_dC', (len(good), N, N))
+                    _lib.check(_lib.lib.vi_cov_f64(h, B, N, dH.ptr, dsel.ptr, dall.offset_ptr(s * N * N)), 'vi_cov_f64')
+                else:
+                    ddC = self._buf('f_dC', (B, N, N))
+                    _lib.check(_lib.lib.vi_cov_f64(h, B, N, dH.ptr, dsel.ptr, ddC.ptr), 'vi_cov_f64')
+                    down(Cov, ddC, s, B, (N, N), np.float64)
+        if compact:
+            return Coeffs, Cov, chi, ranks, good
+        if defer_cov and calccov and len(good):
+            _lib.check(_lib.lib.vi_d2h_side_mark(h), 'vi_d2h_side_mark')
+            dall = self._buf('fd_dC', (len(good), N, N))
+            # runs of consecutive records: one copy each, straight into the rows
+            cut = np.nonzero(np.diff(rows) != 1)[0] + 1
+            runs = list(zip(np.concatenate([[0], cut]).tolist(), np.concatenate([cut, [len(rows)]]).tolist()))
+            err = []
+
+            def bring():
+                try:
+                    for a, b in runs:
+                        if Cov.flags['C_CONTIGUOUS']:
+                            view = Cov[int(rows[a]):int(rows[a]) + (b - a)]
+                            _lib.check(_lib.lib.vi_d2h_side(h, view.ctypes.data_as(_lib.VOIDP), dall.offset_ptr(a * N * N),
+                                                            view.nbytes), 'vi_d2h_side')
+                        else:
+                            tmp = np.empty((b - a, N, N))
+                            _lib.check(_lib.lib.vi_d2h_side(h, tmp.ctypes.data_as(_lib.VOIDP), dall.offset_ptr(a * N * N),
+                                                            tmp.nbytes), 'vi_d2h_side')
+                            Cov[rows[a:b]] = tmp
+                except BaseException as e:          # re-raised by join_cov in the caller's thread
+                    err.append(e)
+            th = threading.Thread(target=bring)
+            th.start()
+            self._cov_pending = (th, err)
         return Coeffs, Cov, chi, ranks
+
+    def join_cov(self):
+        """Wait for the covariance download a finalize(defer_cov=True) left running."""
+        pend, self._cov_pending = getattr(self, '_cov_pending', None), None
+        if pend is not None:
+            pend[0].join()
+            if pend[1]:
+                raise pend[1][0]
 
     CONSISTENCY_TOL = 1e-6        # |chi^2_final - nu| <= tol * nu: the record is reported as consistent
     REDO_TOL = 1e-4               # beyond this the record's root search is redone with cold solves only
@@ -973,8 +1034,26 @@ class FitEngine(object):
         stamp(None)
         params, infos = self.search(npts, prefetch=prefetch, multisection=multisection)
         stamp('search')
-        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov, out=out)
+        # A fit that runs as ONE chain has its covariances come down beside the stream while the guard's solves run (1000
+        # records: 341 -> 331 ms); the pipelines of a split batch fill each other's waits already, and a download thread each
+        # only adds to the host's load there (10 000 records in four pipelines: 2331 ms in line, 2400 beside).
+        # VINTERP_ASYNC_COV=0 / 1 forces either.
+        e = os.environ.get('VINTERP_ASYNC_COV', 'auto')
+        Coeffs, Cov, chi, ranks = self.finalize(params, calccov=calccov, out=out,
+                                                defer_cov=(e == '1' or (e != '0' and out is None)))
         stamp('finalize')
+        cov_rows = []                           # (record, covariance) the guard replaces: written once the download is in
+        try:
+            res = self._guard(npts, calccov, prefetch, params, infos, Coeffs, Cov, chi, ranks, cov_rows, stamp)
+        finally:
+            self.join_cov()
+        for t, row in cov_rows:
+            Cov[t] = row
+        return res
+
+    def _guard(self, npts, calccov, prefetch, params, infos, Coeffs, Cov, chi, ranks, cov_rows, stamp):
+        """The consistency guard of _search_and_finalize; Cov is not touched here (its download may still be running): rows
+        to replace go to cov_rows."""
         if len(self.regularization_list) != 1 or os.environ.get('VINTERP_GUARD', '1') == '0':
             return params, infos, Coeffs, Cov, chi, ranks
         name = self.regularization_list[0]
@@ -1049,11 +1128,13 @@ class FitEngine(object):
                     params[t][name] = float(np.power(10., root))
                     inf['info'][t].update(log10_alpha=root, other_end=oe, polished_cold=True, polish_iterations=iters,
                                           polish_end=how, warm_log10_alpha=float(roots[bad.index(t)]))
-                C2, V2, c2, r2 = self.finalize(params, calccov=calccov, only=set(done))
+                C2, V2, c2, r2, g2 = self.finalize(params, calccov=calccov, only=set(done), compact=True)
+                at = {t: i for i, t in enumerate(g2)}
                 for t in done:
-                    Coeffs[t], chi[t], ranks[t] = C2[t], c2[t], r2[t]
+                    i = at.get(t)
+                    Coeffs[t], chi[t], ranks[t] = (C2[i], c2[i], r2[i]) if i is not None else (np.nan, np.nan, -1)
                     if calccov:
-                        Cov[t] = V2[t]
+                        cov_rows.append((t, V2[i] if i is not None else np.nan))
                 inf['polished_cold'] = done
                 for t in violators():
                     if t in sol:
@@ -1064,15 +1145,17 @@ class FitEngine(object):
         stamp('guard')
         if bad and self.warm_enabled():
             p2, i2 = self.search(npts, prefetch=prefetch, only=bad, cold=True)
-            C2, V2, c2, r2 = self.finalize(p2, calccov=calccov, only=set(bad))
+            C2, V2, c2, r2, g2 = self.finalize(p2, calccov=calccov, only=set(bad), compact=True)
+            at = {t: i for i, t in enumerate(g2)}
             for t in bad:
                 params[t] = p2[t]
                 inf['outcomes'][t] = i2[name]['outcomes'][t]
                 inf['info'][t] = i2[name]['info'][t]
                 inf['info'][t]['redone_cold'] = True
-                Coeffs[t], chi[t], ranks[t] = C2[t], c2[t], r2[t]
+                i = at.get(t)
+                Coeffs[t], chi[t], ranks[t] = (C2[i], c2[i], r2[i]) if i is not None else (np.nan, np.nan, -1)
                 if calccov:
-                    Cov[t] = V2[t]
+                    cov_rows.append((t, V2[i] if i is not None else np.nan))
             inf['evaluations'] += i2[name]['evaluations']
             violators()
         return params, infos, Coeffs, Cov, chi, ranks
