@@ -187,8 +187,8 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // behind the Jacobi kernel's LDS image: coefficients, chi^2 reduction, state
     double* shC = reinterpret_cast<double*>(lds_raw + lds_jacobi);        // [N]
-    double* red = shC + ((N + 1) & ~1);                                    // [512]
-    double* part = red + 512;                                              // [64] partial sums of chi^2, one per block of 256 points
+    double* red = shC + ((N + 1) & ~1);                                    // [768]
+    double* part = red + 768;                                              // [64] partial sums of chi^2, one per block of 256 points
     double* shd = part + 64;                                               // [16] max reduction
     BrentState* st = reinterpret_cast<BrentState*>(shd + 16);
     int* shi = reinterpret_cast<int*>(st + 1);                             // [0] task, [1] sweeps, [2] rounds of the last solve
@@ -268,19 +268,30 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             for (int k = tid; k < N; k += NT) red[k] = cp[k];
             __syncthreads();
             for (int r = tid; r < N; r += NT) {
+                // one fma chain over k, as k_v_vec; the loads of sixteen links are issued before their fmas (left to the
+                // compiler every link waited for its own load: 100 us per function value for 144 x 144 elements)
                 double acc = 0.0;
-                for (int k = 0; k < N; ++k) acc = fma(Vs[(int64_t)k * N + r], red[k], acc);
+                for (int k0 = 0; k0 < N; k0 += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = (k0 + u < N) ? Vs[(int64_t)(k0 + u) * N + r] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (k0 + u < N) acc = fma(v[u], red[k0 + u], acc);
+                }
                 shC[r] = acc;
             }
             __syncthreads();
             BR_STAMP(3);
             // ---- chi^2   (k_chi2_part<256, 1>: one fma chain over n per data point, a fixed tree over the 256 points of a
             //      block; k_chi2_sum: the blocks in order).  Two blocks of points at a time, one per half of 512 threads.
-            for (int b0 = 0; b0 < nb; b0 += 2) {
-                const int half = tid >> 8, t = tid & 255;
-                const int blk = b0 + half;
+            // Three blocks of points at a time (one per 256 threads of the 768; two with 512 threads).
+            const int nbp = NT >> 8;
+            for (int b0 = 0; b0 < nb; b0 += nbp) {
+                const int sub = tid >> 8, t = tid & 255;
+                const int blk = b0 + sub;
                 double v = 0.0;
-                if (tid < 512 && blk < nb) {
+                if (sub < nbp && blk < nb) {
                     const int64_t p = (int64_t)blk * 256 + t;
                     if (p < P) {
                         double acc = 0.0;
@@ -290,13 +301,13 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                         v = d * d * Wr[p];
                     }
                 }
-                if (tid < 512) red[tid] = v;
+                if (sub < nbp) red[tid] = v;
                 __syncthreads();
                 for (int h = 128; h > 0; h >>= 1) {
-                    if (tid < 512 && t < h) red[tid] += red[tid + h];
+                    if (sub < nbp && t < h) red[tid] += red[tid + h];
                     __syncthreads();
                 }
-                if (tid < 512 && t == 0 && blk < nb) part[blk] = red[tid];
+                if (sub < nbp && t == 0 && blk < nb) part[blk] = red[tid];
                 __syncthreads();
             }
             BR_STAMP(4);
@@ -448,7 +459,7 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
     const size_t ldsj = (vi_jacobi_lds_bytes(N) + 15) & ~(size_t)15;
     size_t ldsj2 = wg_gemm_lds_doubles(N) * sizeof(double);
     const size_t ldsj_eff = ldsj > ldsj2 ? ldsj : ((ldsj2 + 15) & ~(size_t)15);
-    const size_t shm = ldsj_eff + ((size_t)((N + 1) & ~1) + 512 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
+    const size_t shm = ldsj_eff + ((size_t)((N + 1) & ~1) + 768 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
 #define VI_B(ITV)                                                                                                             \
     do {                                                                                                                      \
         VI_HIP(hipFuncSetAttribute((const void*)k_brent_warm<ITV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));    \
