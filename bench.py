@@ -9,9 +9,9 @@ sixteen distinct resident records: the number of root-finder iterations (12-60, 
 differs from record to record, so the line reports the mean over the records together with median / min / max and
 the verdicts of the engine's consistency guard.
 Workload "c3" (default at N > 1; BASELINE.json configs[3]): 10000 timesteps of that geometry sharded ceil(T/N) per rank -
-independent records, no data-path collective -, each rank fits its shard as one batch and evaluates it on a 256^3 grid
-with the matrix-core kernel; the evaluation is MEASURED on a tile of 64 of the rank's timesteps and SCALED to its shard
-(a full pass is 150 s per rank at N = 8 and 20 min at N = 1); strong scaling, value = timesteps/s.
+independent records, no data-path collective -, each rank fits its shard as one batch and evaluates EVERY timestep of it
+on a 256^3 grid (basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call), all of it
+inside the timed region; strong scaling, value = timesteps/s over the barrier-to-barrier wall time, max over ranks.
 Inputs (beam geometry, weights/data, query grid, regularisation matrix, hull facets) are resident in HBM before the
 timed region; outputs stay on the device.  Shared parameters are broadcast once from rank 0 over RCCL before the timed
 region; if RCCL was to be used and did not come up, the line says so and the exit status is 3.

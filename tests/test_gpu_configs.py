@@ -210,6 +210,34 @@ def test_pipelines_change_nothing_but_the_time(monkeypatch):
     eng.close()
 
 
+def test_covariances_beside_the_stream_or_in_line_are_the_same(monkeypatch):
+    """The covariances of a fit come down beside the stream while the guard's solves run (vi_d2h_side, a host thread; the
+    default for a fit that runs as one chain) or in line: 100 records - among them records whose search ends without a
+    root (NaN rows) and records the guard re-finalises, whose covariance rows are replaced after the download - give the
+    same arrays either way, as one pipeline and as two."""
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P, T = A.shape[0], 100
+    value, error = synth.synth_records(A, T, seed0=5000)
+    W = error**-2.
+    res = {}
+    for pipes in ('1', '2'):
+        for mode in ('0', '1'):
+            monkeypatch.setenv('VINTERP_PIPELINES', pipes)
+            monkeypatch.setenv('VINTERP_ASYNC_COV', mode)
+            res[pipes, mode] = eng.fit(W, value, [P] * T)
+    ref = res['1', '0']
+    norow = np.isnan(ref['Coeffs'][:, 0])             # records without a root: NaN rows, never downloaded
+    assert norow.any() and not norow.all()
+    assert np.isnan(ref['Covariance'][norow]).all() and np.isfinite(ref['Covariance'][~norow]).all()
+    assert len(ref['search']['curvature'].get('polished_cold', [])) + len(ref['search']['curvature'].get('redone_cold', [])) > 0
+    for key, r in res.items():
+        for name in ('Coeffs', 'Covariance', 'chi_sq'):
+            assert np.array_equal(ref[name], r[name], equal_nan=True), (key, name)
+        assert np.array_equal(ref['ranks'], r['ranks']), key
+    eng.close()
+
+
 def test_largest_in_lds_order_goes_through_the_batched_search(monkeypatch):
     """MAXK 5 x MAXL 6 (N = 180, the largest order the in-LDS solver takes; its rotated systems no longer fit the fused
     form-and-scale kernel): a batch of 10 through the shared-basis walk, the re-basing and the guard - same answers as with
