@@ -142,7 +142,10 @@ int vi_eval_resident_mfma(vi_ctx* c, int N, int64_t Q, int64_t T, const double* 
     if ((Q & 3) != 0 || (((uintptr_t)d_Y | (uintptr_t)d_out) & 31) != 0 || shm > 150 * 1024 || Q < 256) return VI_OK;
     const int ntt = (int)((T + 16 * RT - 1) / (16 * RT));
     // points per workgroup: 256 x groups - the coefficient tile (73 KB through L2) is set up once per workgroup
-    const int groups = Q >= ((int64_t)1 << 22) ? 32 : (Q >= ((int64_t)1 << 18) ? 4 : 1);
+    // (measured, T = 256: 128^3 points 52 TF with 4 groups, 57 with 32; 256^3 the same from 16 up: as many as leave every CU
+    // a few workgroups)
+    int groups = (int)((Q >> 16) < 1 ? 1 : ((Q >> 16) > 32 ? 32 : (Q >> 16)));
+    if (const char* e = getenv("VINTERP_K2R_GROUPS")) { const int g = atoi(e); if (g >= 1 && g <= 256) groups = g; }      // experiments
     const int64_t npg = (Q + (int64_t)256 * groups - 1) / ((int64_t)256 * groups);
     const int64_t nblk = ((npg + 7) / 8) * 8 * ntt;
     if (nblk > 0x7fffffffLL) return VI_OK;
