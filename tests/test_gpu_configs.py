@@ -225,7 +225,13 @@ def test_covariances_beside_the_stream_or_in_line_are_the_same(monkeypatch):
         for mode in ('0', '1'):
             monkeypatch.setenv('VINTERP_PIPELINES', pipes)
             monkeypatch.setenv('VINTERP_ASYNC_COV', mode)
+            before = eng.stats.get('cov_side_downloads', 0), eng.stats.get('cov_side_joined', 0)
             res[pipes, mode] = eng.fit(W, value, [P] * T)
+            # every download started beside the stream was waited for before the fit returned (the guard's own final solves
+            # must not make the engine forget the download it has under way)
+            started = eng.stats.get('cov_side_downloads', 0) - before[0]
+            joined = eng.stats.get('cov_side_joined', 0) - before[1]
+            assert started == joined == (int(pipes) if mode == '1' else 0), (pipes, mode, started, joined)
     ref = res['1', '0']
     norow = np.isnan(ref['Coeffs'][:, 0])             # records without a root: NaN rows, never downloaded
     assert norow.any() and not norow.all()

@@ -912,7 +912,6 @@ class FitEngine(object):
         thread (vi_d2h_side) while the caller goes on launching - self._cov_pending is that thread, to be joined (join_cov)
         before the covariance array is read or written."""
         T, N = self.T, self.N
-        self._cov_pending = None
         good = [t for t in range(T) if (only is None or t in only)
                 and not np.any(np.isnan([params[t][n] for n in self.regularization_list]))]
         if compact:
@@ -976,6 +975,7 @@ class FitEngine(object):
         if compact:
             return Coeffs, Cov, chi, ranks, good
         if defer_cov and calccov and len(good):
+            self.join_cov()                         # (an earlier download of this engine still under way: none, normally)
             _lib.check(_lib.lib.vi_d2h_side_mark(h), 'vi_d2h_side_mark')
             dall = self._buf('fd_dC', (len(good), N, N))
             # runs of consecutive records: one copy each, straight into the rows
@@ -1000,6 +1000,7 @@ class FitEngine(object):
             th = threading.Thread(target=bring)
             th.start()
             self._cov_pending = (th, err)
+            self.stats['cov_side_downloads'] = self.stats.get('cov_side_downloads', 0) + 1
         return Coeffs, Cov, chi, ranks
 
     def join_cov(self):
@@ -1007,6 +1008,7 @@ class FitEngine(object):
         pend, self._cov_pending = getattr(self, '_cov_pending', None), None
         if pend is not None:
             pend[0].join()
+            self.stats['cov_side_joined'] = self.stats.get('cov_side_joined', 0) + 1
             if pend[1]:
                 raise pend[1][0]
 
