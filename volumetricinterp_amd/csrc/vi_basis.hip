@@ -284,8 +284,8 @@ struct EvalSink {
 // Convex-hull test (estimate.py:153-178 semantics: inside <=> max_f (n_f . x + d_f) <= tol), as a mask pass.
 // `hull` is the internal buffer built by k_prep_hull: [c0 (3 doubles, 1 pad)] [F x 4 fp64 facet equations]
 // [F x float4 facets relative to c0].  With ~460 facets an fp64 test inside the evaluation kernel cost twice the
-// whole basis (dependent scalar loads), so the test is its own pass: the fp32 facets are staged in LDS once per
-// workgroup and evaluated relative to a reference point c0 on the plane of facet 0; only lanes within a band of the
+// whole basis (dependent scalar loads), so the test is its own pass: the fp32 facets (wave-uniform scalar loads, see
+// k_hull_mask) are evaluated relative to a reference point c0 on the plane of facet 0; only points within a band of the
 // surface repeat the test in fp64.  The band covers the fp32 error of the prefilter: the float casts of normal and
 // offset plus three FMA roundings are a few units of 2^-24 |x - c0|, and c0 - the foot of the origin's perpendicular
 // on a facet plane - may lie far from the hull when that plane passes near the Earth's centre, so the band grows with
