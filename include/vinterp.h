@@ -294,6 +294,17 @@ int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, double*
                        const int32_t* d_rec, const int32_t* d_slot, const double* d_xa, const double* d_xb,
                        const double* d_fa, const double* d_fb, const double* d_nu, double rcond, double* d_root,
                        double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status);
+/* The same root-finder phase for ONE record, driven from the host in C (the loop of a record fitted alone: one dependent
+ * launch chain per function value, vi_warm_chi2_one_f64, and vi_warm_rebase_f64 + vi_chi2_f64 for the value that moves the
+ * rotated system) - brentq's state machine and the re-basing rule are the ones vi_brent_warm_f64 runs on the device, compiled
+ * for the host: same requests, same values, same root, without an interpreter between a value and the next request.
+ * h_out (host, 6 doubles): root, other end of the final bracket, iterations, function calls, status (0 / 2 / 3 as above),
+ * re-basings.  d_scratch: N + 8 doubles of device memory. */
+int  vi_brent_host_one_f64(vi_ctx* ctx, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt, double* d_V,
+                           const double* d_AWA, const double* d_R, const double* d_y, const double* h_rebase,
+                           const double* d_At, const double* d_W, const double* d_b, int32_t rec, int32_t slot,
+                           double xa, double xb, double fa, double fb, double nu, double rcond, double* d_scratch,
+                           double* h_out);
 /* out[i] = 10^x[i] (host arrays) in plain IEEE operations - the routine the device-side iteration uses, so that host and
  * device form alpha = 10^(log10 alpha) identically (interpolate.py:216, :246) */
 int  vi_exp10_f64(const double* x, double* out, int64_t n);

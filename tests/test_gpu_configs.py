@@ -210,6 +210,36 @@ def test_pipelines_change_nothing_but_the_time(monkeypatch):
     eng.close()
 
 
+def test_single_record_brent_loop_in_c_equals_the_loop_in_python(monkeypatch):
+    """A record fitted alone: Brent's iteration as one library call (vi_brent_host_one_f64, the loop in C with the device
+    kernel's state machine compiled for the host) against the loop in Python with the search coroutine between the function
+    values - alpha, chi^2, coefficients, covariance, iterations and function calls identical, on records that end on a root,
+    on a jump (tens of iterations, two re-basings) and without a root."""
+    from volumetricinterp_amd import synth
+    m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+    P = A.shape[0]
+    value, error = synth.synth_records(A, 16, seed0=1000)            # the sixteen records of bench.py
+    W = error**-2.
+    its = []
+    for t in range(16):
+        res = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('VINTERP_HOST_LOOP_BRENT', mode)
+            res[mode] = eng.fit(W[t:t + 1], value[t:t + 1], [P])
+        a, b = res['0'], res['1']
+        for name in ('Coeffs', 'Covariance', 'chi_sq'):
+            assert np.array_equal(a[name], b[name], equal_nan=True), (t, name)
+        x, y = a['reg_params'][0]['curvature'], b['reg_params'][0]['curvature']
+        assert x == y or (np.isnan(x) and np.isnan(y)), t
+        ia, ib = a['search']['curvature']['info'][0], b['search']['curvature']['info'][0]
+        assert a['search']['curvature']['outcomes'] == b['search']['curvature']['outcomes']
+        if ia:
+            assert ia.get('iterations') == ib.get('iterations') and ia.get('other_end') == ib.get('other_end'), t
+            its.append(ia.get('iterations', 0))
+    assert max(its) >= 30 and min(its) <= 16            # a jump record and ordinary ones were among them
+    eng.close()
+
+
 def test_covariances_beside_the_stream_or_in_line_are_the_same(monkeypatch):
     """The covariances of a fit come down beside the stream while the guard's solves run (vi_d2h_side, a host thread; the
     default for a fit that runs as one chain) or in line: 100 records - among them records whose search ends without a

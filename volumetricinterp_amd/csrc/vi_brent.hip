@@ -25,6 +25,7 @@
 #include "vi_exp10.h"
 
 #include <cstdlib>
+#include <cstring>
 
 size_t vi_jacobi_lds_bytes(int N);
 size_t vi_jacobi_log_bytes(int N, int max_sweeps);
@@ -64,7 +65,7 @@ struct RebaseRule {
     int again_on;
 };
 
-__device__ __forceinline__ void rebase_decide(BrentState& s, const RebaseRule& rr)
+__host__ __device__ __forceinline__ void rebase_decide(BrentState& s, const RebaseRule& rr)
 {
     const double x = s.xcur;
     bool rb = false;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void rebase_decide(BrentState& s, const RebaseRule& r
 
 // brentq_gen from the top of its loop to the next request (alpha_search.py: BrentBatch._top for one record); returns true
 // when the iteration has ended (root in xcur, other end in xblk).
-__device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rtol)
+__host__ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rtol)
 {
 #pragma clang fp contract(off)
     if (s.fpre != 0.0 && s.fcur != 0.0 && (signbit(s.fpre) != signbit(s.fcur))) {
@@ -407,6 +408,107 @@ extern "C" int vi_debug_brent_stamps(double* out, int reset)
 extern "C" int vi_exp10_f64(const double* x, double* out, int64_t n)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = vi_exp10(x[i]);
+    return VI_OK;
+}
+
+// Brent's iteration (interpolate.py:214) of ONE record driven from the host, in C: the loop of FitEngine's host-driven path for a
+// record fitted alone - the same state machine (brent_top / rebase_decide, compiled for the host), the same calls per function
+// value (vi_warm_chi2_one_f64; vi_warm_rebase_f64 + vi_chi2_f64 for the value that moves the rotated system) - without the
+// interpreter between a value and the next request (~35 us of each ~135 us a dependent iterate spends outside its solve).
+// h_out: root, other end, iterations, function calls, status (0 converged, 2 a solve hit the sweep cap - the caller runs the
+// record's iteration itself -, 3 maxiter), re-basings.  d_scratch: N + 8 doubles.
+extern "C" int vi_warm_chi2_one_f64(vi_ctx* c, int32_t N, int64_t P, const double* d_D1, const double* d_D2, const double* d_yt,
+                                    const double* d_V, int32_t slot, double alpha, double rcond, const double* d_At, int32_t rec,
+                                    const double* d_W, const double* d_b, double* d_scratch, double* h_chi2);
+extern "C" int vi_warm_rebase_f64(vi_ctx* c, int64_t B, int64_t nplain, int32_t N, const double* d_AWA, const double* d_R,
+                                  const double* d_y, const int32_t* d_rec, const int32_t* d_slot, const double* d_alpha,
+                                  double rcond, double* d_V, double* d_D1, double* d_D2, double* d_yt, double* d_C,
+                                  int32_t* d_rank, int32_t* d_sweeps);
+extern "C" int vi_chi2_f64(vi_ctx* c, int64_t B, int64_t P, int32_t N, const double* d_At, const double* d_C,
+                           const int32_t* d_rec, const double* d_W, const double* d_b, double* d_chi2);
+namespace {
+__global__ void k_set_one_b(double* scratch, double alpha, int slot, int rec)
+{
+    scratch[0] = alpha;
+    int* iv = reinterpret_cast<int*>(scratch + 2);
+    iv[0] = slot;
+    iv[1] = rec;
+}
+}  // namespace
+
+extern "C" int vi_brent_host_one_f64(vi_ctx* c, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt, double* d_V,
+                                     const double* d_AWA, const double* d_R, const double* d_y, const double* h_rebase,
+                                     const double* d_At, const double* d_W, const double* d_b, int32_t rec, int32_t slot,
+                                     double xa, double xb, double fa, double fb, double nu, double rcond, double* d_scratch,
+                                     double* h_out)
+{
+    VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_AWA && d_R && d_y && h_rebase && d_At && d_W && d_b && d_scratch && h_out,
+               "null argument");
+    VI_REQUIRE(N > 0 && P > 0 && rec >= 0 && slot >= 0, "bad size");
+    VI_HIP(hipSetDevice(c->device));
+    RebaseRule rr;
+    rr.nsched = (int)h_rebase[0];
+    if (rr.nsched < 0 || rr.nsched > 4) { vi_set_error("vi_brent_host_one_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
+    for (int i = 0; i < 4; ++i) rr.sched[i] = h_rebase[1 + i];
+    rr.again_after = (int)h_rebase[5];
+    rr.again_within = h_rebase[6];
+    rr.again_on = (int)h_rebase[7];
+    const double xtol = 2e-12, rtol = 4 * 2.220446049250313e-16;
+    const int maxiter = 100, max_sweeps = vi_max_sweeps();
+    BrentState s;
+    s.xpre = xa; s.xcur = xb; s.fpre = fa; s.fcur = fb;
+    s.xblk = s.fblk = s.spre = s.scur = 0.0;
+    s.it = 1; s.funcalls = 0; s.status = 0;
+    s.last_x = __builtin_nan("");
+    s.nreq = 0; s.rebased = 0; s.rebase_now = 0;
+    s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+    if (!s.done) rebase_decide(s, rr);
+    double* d_alpha = d_scratch;
+    double* d_chi = d_scratch + 1;
+    int32_t* d_slot = reinterpret_cast<int32_t*>(d_scratch + 2);
+    int32_t* d_rec = d_slot + 1;
+    int32_t* d_sw = reinterpret_cast<int32_t*>(d_scratch + 3);
+    double* d_C = d_scratch + 8;
+    while (!s.done) {
+        const double alpha = vi_exp10(s.xcur);
+        double back[3] = {0.0, 0.0, 0.0};
+        int rc;
+        if (s.rebase_now) {
+            hipLaunchKernelGGL(k_set_one_b, dim3(1), dim3(1), 0, c->stream, d_scratch, alpha, (int)slot, (int)rec);
+            VI_HIP(hipGetLastError());
+            rc = vi_warm_rebase_f64(c, 1, 0, N, d_AWA, d_R, d_y, d_rec, d_slot, d_alpha, rcond, d_V, d_D1, d_D2, d_yt, d_C, nullptr,
+                                    d_sw);
+            if (rc != VI_OK) return rc;
+            rc = vi_chi2_f64(c, 1, P, N, d_At, d_C, d_rec, d_W, d_b, d_chi);
+            if (rc != VI_OK) return rc;
+            VI_HIP(hipMemcpyAsync(back, d_chi, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            VI_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            rc = vi_warm_chi2_one_f64(c, N, P, d_D1, d_D2, d_yt, d_V, slot, alpha, rcond, d_At, rec, d_W, d_b, d_scratch, back);
+            if (rc != VI_OK) return rc;
+        }
+        int sweeps;
+        memcpy(&sweeps, &back[2], sizeof(int));
+        if (sweeps > max_sweeps) {
+            s.status = 2;
+            break;
+        }
+        s.fcur = back[0] - nu;
+        s.funcalls += 1;
+        s.it += 1;
+        if (s.it > maxiter) {
+            s.status = 3;
+            break;
+        }
+        s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+        if (!s.done) rebase_decide(s, rr);
+    }
+    h_out[0] = s.xcur;
+    h_out[1] = s.xblk;
+    h_out[2] = (double)s.it;
+    h_out[3] = (double)s.funcalls;
+    h_out[4] = (double)s.status;
+    h_out[5] = (double)s.rebased;
     return VI_OK;
 }
 

@@ -69,7 +69,9 @@ _lib._sig('vi_gcv_terms_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int64, C.c_int
 _lib._sig('vi_eigvals_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
 _lib._sig('vi_qr_similarity_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP,
           _lib.VOIDP)
-_lib.EXPORTS += ['vi_brent_warm_f64', 'vi_exp10_f64', 'vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib._sig('vi_brent_host_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, *([_lib.VOIDP] * 11), C.c_int32, C.c_int32,
+          C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _lib.VOIDP, _lib.VOIDP)
+_lib.EXPORTS += ['vi_brent_host_one_f64', 'vi_brent_warm_f64', 'vi_exp10_f64', 'vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -685,6 +687,55 @@ class FitEngine(object):
             self.stats['unconverged_resolved'] = self.stats.get('unconverged_resolved', 0) + int((sts == 2).sum())
         return [(float(root[j]), int(its[j]), int(fcs[j]), float(other[j])) if sts[j] == 0 else None for j in range(n)]
 
+    def host_loop_brent_enabled(self):
+        """Brent's iteration of a record fitted ALONE as one library call (vi_brent_host_one_f64: the host-driven loop in C,
+        the state machine of the device kernel compiled for the host) instead of one call per function value with the search
+        coroutine in between: same requests, same values, same bits.  VINTERP_HOST_LOOP_BRENT=0 keeps the loop in Python."""
+        if os.environ.get('VINTERP_HOST_LOOP_BRENT', '1') == '0' or not self.warm_enabled() or len(self.regularization_list) != 1:
+            return False
+        return self.T == 1 and len(self._rebase_schedule()) <= 4
+
+    def _host_loop_brent(self, recs, brackets, name):
+        """_device_brent's contract for the records of a fit that is driven from the host (one record)."""
+        N, h = self.N, self.ctx.handle
+        out = []
+        sched = list(self._rebase_schedule()) if os.environ.get('VINTERP_REBASE', '1') != '0' else []
+        rule = np.array([len(sched)] + (sched + [0.] * 4)[:4] + [self.REBASE_AGAIN_AFTER, self.REBASE_AGAIN_WITHIN,
+                        1. if (sched and os.environ.get('VINTERP_REBASE2', '1') != '0') else 0.], dtype=np.float64)
+        for r, b in zip([int(r) for r in recs], brackets):
+            if r not in self._warm_slot:
+                # the rotated system at the middle of the record's unit bracket: decomposed alongside the walk, or now
+                mid = math.floor(min(b['alpha'], b['alpha0'])) + 0.5
+                self._basis_x[r] = mid
+                if (r, mid) in self._spec_slot:
+                    self._finish_speculative(r, self._spec_slot[(r, mid)])
+                else:
+                    scratchC = self._buf('wp_scratchC', (1, N))
+                    scratchR = self._buf('wp_scratchR', (1,), np.int32)
+                    self._warm_prepare('w_', self._warm_slot, [r], [float(np.power(10., mid))], name, scratchC.ptr, scratchR.ptr)
+                    self.stats['solves'] += 1
+            dV, dD1, dD2, dyt = self._warm_buffers('w_')
+            scratch = self._buf('w_one', (N + 8,))
+            res = np.zeros(6)
+            _lib.check(_lib.lib.vi_brent_host_one_f64(h, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, self.dAWA.ptr,
+                                                      self.R[name].ptr, self.dy.ptr, rule.ctypes.data_as(_lib.VOIDP), self.At.ptr,
+                                                      self.dW.ptr, self.db.ptr, r, self._warm_slot[r], float(b['alpha']),
+                                                      float(b['alpha0']), float(b['val']), float(b['val0']), float(b['nu']), EPS,
+                                                      scratch.ptr, res.ctypes.data_as(_lib.VOIDP)), 'vi_brent_host_one_f64')
+            st, fc = int(res[4]), int(res[3])
+            if st == 3:
+                raise RuntimeError('Failed to converge after %d iterations.' % alpha_search.MAXITER)
+            self.stats['solves'] += fc
+            self.stats['launches'] += fc
+            self.stats['warm_solves'] = self.stats.get('warm_solves', 0) + fc
+            self.stats['rebased'] = self.stats.get('rebased', 0) + int(res[5])
+            if st == 2:
+                self.stats['unconverged_resolved'] = self.stats.get('unconverged_resolved', 0) + 1
+                out.append(None)
+            else:
+                out.append((float(res[0]), int(res[2]), fc, float(res[1])))
+        return out
+
     @staticmethod
     def _exp10(x):
         """10^x for one root-finder abscissa by the library's routine (see _chi2_batch_search_raw)."""
@@ -841,6 +892,9 @@ class FitEngine(object):
             if self.device_brent_enabled() and not cold and not multisection:
                 def solver(recs, brs, _name=name):
                     return self._device_brent(recs, brs, _name)
+            elif self.host_loop_brent_enabled() and not cold and not multisection:
+                def solver(recs, brs, _name=name):
+                    return self._host_loop_brent(recs, brs, _name)
             if not multisection and T >= 16 and os.environ.get('VINTERP_TABLE_WALK', '1') != '0':
                 # the walks of the whole batch on one (records x decades) table: the coroutines' requests and decisions
                 # without the coroutines (110 ms of interpreter per 1000 records, which concurrent pipelines cannot share)
