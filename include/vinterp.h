@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define VI_ABI_VERSION 1
+/* 2 (round 4): vi_warm_solve_f64 / vi_basis_solve_f64 / vi_warm_rebase_f64 take a trailing d_sweeps pointer,
+ * vi_warm_chi2_one_f64 writes THREE doubles to h_chi2, vi_brent_warm_supported added.  _lib.py refuses any other version. */
+#define VI_ABI_VERSION 2
 
 typedef enum vi_status {
     VI_OK = 0,
@@ -294,6 +296,11 @@ int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, double*
                        const int32_t* d_rec, const int32_t* d_slot, const double* d_xa, const double* d_xb,
                        const double* d_fa, const double* d_fb, const double* d_nu, double rcond, double* d_root,
                        double* d_other, int32_t* d_iters, int32_t* d_funcalls, int32_t* d_status);
+/* 1 when vi_brent_warm_f64 serves order N with P data points per record (in-LDS Jacobi range, and the chi^2 partial sums of
+ * a record - one per 256 points - fit beside its system in a CU's LDS: P <= ~2 million at N = 144), else 0: drive Brent's
+ * iteration from the host then (vi_warm_solve_f64 + vi_chi2_f64), which has no such limit - the reference accepts any P
+ * (interpolate.py:214). */
+int  vi_brent_warm_supported(int32_t N, int64_t P);
 /* The same root-finder phase for ONE record, driven from the host in C (the loop of a record fitted alone: one dependent
  * launch chain per function value, vi_warm_chi2_one_f64, and vi_warm_rebase_f64 + vi_chi2_f64 for the value that moves the
  * rotated system) - brentq's state machine and the re-basing rule are the ones vi_brent_warm_f64 runs on the device, compiled

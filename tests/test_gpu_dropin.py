@@ -101,9 +101,9 @@ def test_config_to_hdf5_to_estimate(tmp_path):
     it2.calc_coeffs(starttime=dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(f['utime'][1, 0])),
                     endtime=dt.datetime(1970, 1, 1) + dt.timedelta(seconds=float(f['utime'][2, 1])))
     assert it2.Coeffs.shape == (2, 32)
-    # same record in a batch of 2 instead of 3: the guarded multisection samples other abscissae (K = 256 // T - 1), so
-    # the root moves within its 1e-10 resolution in log10 alpha - far inside the 1e-6 budget
-    assert rel(it2.Coeffs[1], it.Coeffs[2]) <= 1e-7
+    # the same record in a batch of 2 instead of 3: a record's answer does not depend on the batch it is fitted in (the
+    # multisection's sample count is independent of T since round 3), bit for bit
+    assert np.array_equal(it2.Coeffs[1], it.Coeffs[2])
 
 
 def _write_amisr(path, f, T):
@@ -155,8 +155,8 @@ def test_cli_two_ranks_equal_one(tmp_path):
     assert one.Coeffs.shape == two.Coeffs.shape == (T, 32)
     np.testing.assert_array_equal(one.time, two.time)
     for t in range(T):
-        # 2 records per rank instead of 4: the guarded multisection samples other abscissae (K = 256 // T - 1)
-        assert rel(two.Coeffs[t], one.Coeffs[t]) <= 1e-7, t
+        # 2 records per rank instead of 4 in one process: the same bits (records do not see each other)
+        assert np.array_equal(two.Coeffs[t], one.Coeffs[t]), t
         assert rel(two.Coeffs[t], f['Coeffs'][t]) <= 1e-6, t
 
 

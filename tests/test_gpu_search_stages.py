@@ -303,3 +303,29 @@ def test_device_brent_equals_host_brent(monkeypatch):
             assert np.array_equal(dev['Coeffs'][t], host['Coeffs'][t], equal_nan=True), (rebase, t)
             assert dev['chi_sq'][t] == host['chi_sq'][t] or np.isnan(a1)
     eng.close()
+
+
+def test_device_brent_with_more_than_16384_points_per_record(monkeypatch):
+    """Records of 65 x 256 = 16 640 data points (65 blocks of chi^2 partial sums per record; until round 4 the kernel held 64 and
+    the DEFAULT path of a batch of >= 8 records raised at this size - the reference accepts any P, interpolate.py:214).  Eight
+    records through the default batch path (device-side Brent) and through the host-driven iteration: same bits."""
+    from volumetricinterp_amd import _lib, synth
+    geom = (65, 256)
+    assert _lib.lib.vi_brent_warm_supported(144, geom[0] * geom[1]) == 1
+    m, ctx, eng, A, _ = _engine(CFG144, geom)
+    P, T = A.shape[0], 8
+    assert P > 16384
+    value, error = synth.synth_records(A, T, seed0=8100)
+    W = error**-2.
+    n0 = eng.stats.get('device_brent_records', 0)
+    dev = eng.fit(W, value, [P] * T)                                   # no environment switch: what a user gets
+    nroot = dev['search']['curvature']['outcomes'].count('root')
+    assert nroot >= 1 and eng.stats.get('device_brent_records', 0) - n0 >= 1
+    monkeypatch.setenv('VINTERP_DEVICE_BRENT', '0')
+    host = eng.fit(W, value, [P] * T)
+    monkeypatch.delenv('VINTERP_DEVICE_BRENT')
+    for t in range(T):
+        a1, a2 = dev['reg_params'][t]['curvature'], host['reg_params'][t]['curvature']
+        assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (t, a1, a2)
+        assert np.array_equal(dev['Coeffs'][t], host['Coeffs'][t], equal_nan=True), t
+    eng.close()

@@ -74,4 +74,27 @@ def test_psi_by_gauss_quadrature_matches_the_reference():
         assert np.max(np.abs(P - R)) <= 5e-10 * np.max(np.abs(R)), tag
         P2 = regmat.eval_psi_gauss(m, ntheta=1200)
         assert np.max(np.abs(P - P2)) <= 1e-13 * np.max(np.abs(P))
-        assert np.array_equal(m.eval_reg_matricies['0thorder'](), P)        # what the plug-in hands to the fit
+
+
+
+def test_default_psi_is_the_reference_s_and_finite_limits_converge(monkeypatch):
+    """What the plug-in hands to the fit by default is the reference's own Psi BIT FOR BIT (regmat.eval_psi: its integrands and
+    quad calls); the Gauss-quadrature variant is opt-in (VINTERP_REGMAT=gauss).  With a FINITE MAX_Z_INT - small, or 1e3 used
+    as 'practically infinite' (a fixed Gauss-Legendre rule was unconverged there) - the opt-in variant agrees
+    with the QUADPACK restatement to 5e-10 of max|Psi| as well."""
+    import io
+    from conftest import load_golden
+    from volumetricinterp_amd import regmat
+    from volumetricinterp_amd.models.sphharmlag import Model
+    ref = load_golden('regmat')
+    cfg = ('[DEFAULT]\n[MODEL]\nNAME = sphharmlag\nMAXK = %d\nMAXL = %d\nCAP_LIM = 10\nMAX_Z_INT = %s\nLATCP = 78\n'
+           'LONCP = 262\n')
+    monkeypatch.delenv('VINTERP_REGMAT', raising=False)
+    m = Model(io.StringIO(cfg % (8, 2, 'INF')))
+    assert np.array_equal(m.eval_reg_matricies['0thorder'](), ref['k8l2_0thorder'])
+    monkeypatch.setenv('VINTERP_REGMAT', 'gauss')
+    assert np.array_equal(m.eval_reg_matricies['0thorder'](), regmat.eval_psi_gauss(m))
+    for zmax in ('3', '40', '1000'):
+        mf = Model(io.StringIO(cfg % (4, 3, zmax)))
+        Pq, Pg = regmat.eval_psi(mf), regmat.eval_psi_gauss(mf)
+        assert np.max(np.abs(Pg - Pq)) <= 5e-10 * np.max(np.abs(Pq)), zmax

@@ -35,6 +35,12 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 HW_QUEUES_REQUESTED = os.environ['GPU_MAX_HW_QUEUES']
 
 lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+ABI_VERSION = 2                 # include/vinterp.h VI_ABI_VERSION: the signatures bound below and in fitengine.py
+lib.vi_abi_version.restype = C.c_int
+if lib.vi_abi_version() != ABI_VERSION:
+    raise ImportError('volumetricinterp_amd: %s reports ABI version %d, this package binds version %d - rebuild it '
+                      '(`make -C %s`)%s' % (LIB_PATH, lib.vi_abi_version(), ABI_VERSION, os.path.join(_HERE, 'csrc'),
+                                            '; VINTERP_LIB points at it' if os.environ.get('VINTERP_LIB') else ''))
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -183,14 +183,14 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
     const double* __restrict__ t_nu, double rcond, double abs_floor, int max_sweeps, double xtol, double rtol, int maxiter,
     int* __restrict__ queue, double* __restrict__ Xw, double2* __restrict__ logw, int64_t log_stride, double* __restrict__ cw,
     double* __restrict__ o_root, double* __restrict__ o_other, int* __restrict__ o_iters, int* __restrict__ o_funcalls,
-    int* __restrict__ o_status, size_t lds_jacobi, unsigned long long* __restrict__ round_acc)
+    int* __restrict__ o_status, size_t lds_jacobi, int npart, unsigned long long* __restrict__ round_acc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // behind the Jacobi kernel's LDS image: coefficients, chi^2 reduction, state
     double* shC = reinterpret_cast<double*>(lds_raw + lds_jacobi);        // [N]
     double* red = shC + ((N + 1) & ~1);                                    // [768]
-    double* part = red + 768;                                              // [64] partial sums of chi^2, one per block of 256 points
-    double* shd = part + 64;                                               // [16] max reduction
+    double* part = red + 768;                                              // [npart] partial sums of chi^2, one per block of 256 points
+    double* shd = part + npart;                                            // [16] max reduction
     BrentState* st = reinterpret_cast<BrentState*>(shd + 16);
     int* shi = reinterpret_cast<int*>(st + 1);                             // [0] task, [1] sweeps, [2] rounds of the last solve
 
@@ -334,7 +334,13 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             }
             __syncthreads();
             BR_STAMP(5);
-            if (st->rebase_now && st->status == 0 && !st->done) {
+            // every wave takes its copy of the decision BEFORE lane 0 may write the next iterate's flags (rebase_decide below):
+            // a wave that read st->rebase_now late could otherwise see the next iterate's 1 and enter rebase_call - which holds
+            // barriers - alone
+            const bool do_rebase = st->rebase_now && st->status == 0 && !st->done;
+            const bool done_now = st->done != 0;
+            __syncthreads();
+            if (do_rebase) {
                 // ---- move the rotated system to this iterate's alpha (vi_warm_rebase_f64): eigenvectors Vw of the rotated
                 //      system out of the rotation log of the solve just done, V <- V Vw, and D1 = V^T AWA V, D2 = V^T R V,
                 //      yt = V^T y from the untransformed matrices - the host path's kernels, the host path's order
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                             );
                 BR_STAMP(7);
             }
-            if (tid == 0 && !st->done) {
+            if (tid == 0 && !done_now) {
                 BrentState s = *st;
                 rebase_decide(s, rr);
                 *st = s;
@@ -377,7 +383,30 @@ void brent_geometry(int N, int& threads, int& it)
     }
 }
 
+// LDS of a k_brent_warm workgroup: the Jacobi image (or the product scratch of a re-basing, whichever is larger), the
+// coefficients, the chi^2 reduction tree, one partial sum per block of 256 data points, the state.
+constexpr size_t VI_LDS_BYTES_PER_CU = 160 * 1024;
+size_t brent_lds_bytes(int N, int64_t P, size_t* ldsj_eff, int* npart)
+{
+    const size_t ldsj = (vi_jacobi_lds_bytes(N) + 15) & ~(size_t)15;
+    const size_t ldsj2 = wg_gemm_lds_doubles(N) * sizeof(double);
+    const size_t eff = ldsj > ldsj2 ? ldsj : ((ldsj2 + 15) & ~(size_t)15);
+    const int64_t nb = (P + 255) / 256;
+    const int64_t np = nb < 64 ? 64 : ((nb + 1) & ~(int64_t)1);
+    if (ldsj_eff) *ldsj_eff = eff;
+    if (npart) *npart = (int)(np > (1 << 20) ? (1 << 20) : np);
+    return eff + ((size_t)((N + 1) & ~1) + 768 + (size_t)np + 16) * sizeof(double) + sizeof(BrentState) + 64;
+}
+
 }  // namespace
+
+// 1 when vi_brent_warm_f64 serves this order and record size (in-LDS Jacobi range; the chi^2 partial sums of P points fit
+// beside the system in one CU's LDS), 0 otherwise: the caller then drives Brent's iteration from the host, which has no limit.
+extern "C" int vi_brent_warm_supported(int32_t N, int64_t P)
+{
+    if (N <= 0 || P <= 0 || !vi_jacobi_supported(N)) return 0;
+    return brent_lds_bytes(N, P, nullptr, nullptr) <= VI_LDS_BYTES_PER_CU ? 1 : 0;
+}
 
 #ifdef VI_STAMPS
 extern "C" int vi_debug_brent_hist(double* out, int reset)
@@ -527,6 +556,7 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
 {
     const double abs_floor = vi_floor_warm();
     const int max_sweeps = vi_max_sweeps();
+    size_t ldsj_eff;
     VI_REQUIRE(c && d_D1 && d_D2 && d_yt && d_V && d_AWA && d_R && d_y && h_rebase && d_At && d_W && d_b && d_rec && d_slot && d_xa && d_xb && d_fa && d_fb && d_nu &&
                    d_root && d_other && d_iters && d_funcalls && d_status, "null argument");
     VI_REQUIRE(ntask >= 0 && N > 0 && P > 0, "bad size");
@@ -535,7 +565,13 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
         vi_set_error("vi_brent_warm_f64: N=%d outside the in-LDS Jacobi range", N);
         return VI_ERR_UNSUPPORTED;
     }
-    VI_REQUIRE((P + 255) / 256 <= 64, "more than 16384 data points per record");
+    int npart;
+    const size_t shm = brent_lds_bytes(N, P, &ldsj_eff, &npart);
+    if (shm > VI_LDS_BYTES_PER_CU) {
+        vi_set_error("vi_brent_warm_f64: %lld data points per record need %zu bytes of LDS (the chi^2 partial sums of a record "
+                     "sit beside its rotated system); the host-driven iteration has no such limit", (long long)P, shm);
+        return VI_ERR_UNSUPPORTED;
+    }
     VI_HIP(hipSetDevice(c->device));
     int threads, it;
     brent_geometry(N, threads, it);
@@ -558,17 +594,13 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
     rr.again_on = (int)h_rebase[7];
     int* queue = (int*)(cw + (size_t)nwg * N + 1);
     VI_HIP(hipMemsetAsync(queue, 0, sizeof(int), c->stream));
-    const size_t ldsj = (vi_jacobi_lds_bytes(N) + 15) & ~(size_t)15;
-    size_t ldsj2 = wg_gemm_lds_doubles(N) * sizeof(double);
-    const size_t ldsj_eff = ldsj > ldsj2 ? ldsj : ((ldsj2 + 15) & ~(size_t)15);
-    const size_t shm = ldsj_eff + ((size_t)((N + 1) & ~1) + 768 + 64 + 16) * sizeof(double) + sizeof(BrentState) + 64;
 #define VI_B(ITV)                                                                                                             \
     do {                                                                                                                      \
         VI_HIP(hipFuncSetAttribute((const void*)k_brent_warm<ITV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));    \
         hipLaunchKernelGGL(k_brent_warm<ITV>, dim3((unsigned)nwg), dim3(threads), shm, c->stream, N, P, (int)ntask, d_D1, d_D2, \
                            d_yt, d_V, d_AWA, d_R, d_y, rr, VwW, VnW, d_At, d_W, d_b, d_rec, d_slot, d_xa, d_xb, d_fa, d_fb, d_nu, rcond, abs_floor,          \
                            (int)max_sweeps, 2e-12, 4 * 2.220446049250313e-16, 100, queue, Xw, logw,                           \
-                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj_eff, \
+                           (int64_t)(logb / sizeof(double2)), cw, d_root, d_other, d_iters, d_funcalls, d_status, ldsj_eff, npart, \
                            c->solve_timing ? c->d_rounds : nullptr);                                                        \
     } while (0)
     // (vi_solve_timing: the launch counts among the eigen-solve launches - it is one, record after record)

@@ -9,7 +9,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VI_HD __host__ __device__
 #else
 #define VI_HD

@@ -252,22 +252,29 @@ class ResidentGrid(object):
         if self.Q * N * 8 > 0.9 * free:
             raise MemoryError('basis matrix of %d points x %d functions (%.1f GB) does not fit the device (%.1f GB free)'
                               % (self.Q, N, self.Q * N * 8 / 1e9, free / 1e9))
-        self.dY = ctx.empty((N, self.Q))
-        if self.Q == 0:
-            return
-        d = [ctx.to_device(a) for a in (lat, lon, alt)]
-        if check_hull:
-            eq, tol = est._hull()
-            dh, F = ctx.to_device(eq), eq.shape[0]
-        else:
-            dh, F, tol = None, 0, 0.
-        _lib.check(_lib.lib.vi_eval_basis_f64(est.model.handle(), self.Q, d[0].ptr, d[1].ptr, d[2].ptr,
-                                              dh.ptr if dh is not None else None, F, tol, self.dY.ptr), 'vi_eval_basis_f64')
-        ctx.sync()
-        for a in d:
-            a.free()
-        if dh is not None:
-            dh.free()
+        self.dY = None
+        tmp = []                        # device temporaries of the set-up: freed whatever happens below
+        try:
+            self.dY = ctx.empty((N, self.Q))
+            if self.Q == 0:
+                return
+            for a in (lat, lon, alt):
+                tmp.append(ctx.to_device(a))
+            if check_hull:
+                eq, tol = est._hull()
+                dh, F = ctx.to_device(eq), eq.shape[0]
+                tmp.append(dh)
+            else:
+                dh, F, tol = None, 0, 0.
+            _lib.check(_lib.lib.vi_eval_basis_f64(est.model.handle(), self.Q, tmp[0].ptr, tmp[1].ptr, tmp[2].ptr,
+                                                  dh.ptr if dh is not None else None, F, tol, self.dY.ptr), 'vi_eval_basis_f64')
+            ctx.sync()
+        except BaseException:
+            self.close()                # the basis matrix (19 GB at the default order on 256^3) must not outlive a failed set-up
+            raise
+        finally:
+            for a in tmp:
+                a.free()
 
     def evaluate_coeffs(self, C, out=None):
         """out[t] = density of coefficient row C[t] on the grid; (T, Q) host array."""
@@ -286,15 +293,21 @@ class ResidentGrid(object):
         # timesteps in slabs whose output fits a quarter of the free device memory
         free, _ = ctx.mem_info()
         slab = int(max(1, min(T, (free // 4) // max(1, self.Q * 8))))
-        dC = ctx.to_device(C)
-        dO = ctx.empty((slab, self.Q))
-        for t0 in range(0, T, slab):
-            tc = min(slab, T - t0)
-            _lib.check(_lib.lib.vi_eval_resident_f64(self.est.model.handle(), self.Q, tc, self.dY.ptr, dC.offset_ptr(t0 * N),
-                                                     dO.ptr), 'vi_eval_resident_f64')
-            _lib.check(_lib.lib.vi_d2h(ctx.handle, out[t0:t0 + tc].ctypes.data_as(_lib.VOIDP), dO.ptr, tc * self.Q * 8), 'd2h')
-        dC.free()
-        dO.free()
+        if self.dY is None:
+            raise ValueError('this ResidentGrid has been closed')
+        dC = dO = None
+        try:
+            dC = ctx.to_device(C)
+            dO = ctx.empty((slab, self.Q))
+            for t0 in range(0, T, slab):
+                tc = min(slab, T - t0)
+                _lib.check(_lib.lib.vi_eval_resident_f64(self.est.model.handle(), self.Q, tc, self.dY.ptr, dC.offset_ptr(t0 * N),
+                                                         dO.ptr), 'vi_eval_resident_f64')
+                _lib.check(_lib.lib.vi_d2h(ctx.handle, out[t0:t0 + tc].ctypes.data_as(_lib.VOIDP), dO.ptr, tc * self.Q * 8), 'd2h')
+        finally:
+            for a in (dC, dO):
+                if a is not None:
+                    a.free()
         return out
 
     def __call__(self, times):
@@ -303,6 +316,21 @@ class ResidentGrid(object):
         return self.evaluate_coeffs(C).reshape((len(times),) + tuple(self.shape))
 
     def close(self):
-        if self.dY is not None:
-            self.dY.free()
-            self.dY = None
+        """Give the basis matrix back to the device (idempotent).  Also runs on `with est.resident_grid(...) as g:` exit
+        and when the object is collected."""
+        dY, self.dY = getattr(self, 'dY', None), None
+        if dY is not None:
+            dY.free()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:               # interpreter shutdown: the library may already be gone
+            pass

@@ -71,7 +71,8 @@ _lib._sig('vi_qr_similarity_f64', C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _li
           _lib.VOIDP)
 _lib._sig('vi_brent_host_one_f64', C.c_int, _lib.VOIDP, C.c_int32, C.c_int64, *([_lib.VOIDP] * 11), C.c_int32, C.c_int32,
           C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _lib.VOIDP, _lib.VOIDP)
-_lib.EXPORTS += ['vi_brent_host_one_f64', 'vi_brent_warm_f64', 'vi_exp10_f64', 'vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
+_lib._sig('vi_brent_warm_supported', C.c_int, C.c_int32, C.c_int64)
+_lib.EXPORTS += ['vi_brent_warm_supported', 'vi_brent_host_one_f64', 'vi_brent_warm_f64', 'vi_exp10_f64', 'vi_max_sweeps', 'vi_qr_similarity_f64', 'vi_rotation_log_bytes', 'vi_decompose_f64', 'vi_warm_finish_f64', 'vi_warm_rebase_f64', 'vi_reg_floor_f64', 'vi_basis_solve_f64', 'vi_warm_chi2_one_f64', 'vi_gcv_terms_f64', 'vi_warm_prepare_f64', 'vi_warm_solve_f64', 'vi_eigvals_f64', 'vi_normal_eq_f64', 'vi_form_system_f64', 'vi_solve_trunc_f64', 'vi_chi2_f64', 'vi_cov_f64']
 
 MAX_BATCH = 8192          # systems per solver launch (N=144: 1.3 GB of X)
 
@@ -635,6 +636,10 @@ class FitEngine(object):
             return False
         if len(self._rebase_schedule()) > 4:
             return False
+        if not _lib.lib.vi_brent_warm_supported(self.N, self.P):
+            # records with so many data points that their chi^2 partial sums do not fit beside the system in a CU's LDS: the
+            # host-driven rounds, which have no limit (the reference accepts any P)
+            return False
         return e == '1' or self.T >= self.DEVICE_BRENT_MIN_RECORDS
 
     def _device_brent(self, recs, brackets, name):
@@ -1101,8 +1106,15 @@ class FitEngine(object):
         cov_rows = []                           # (record, covariance) the guard replaces: written once the download is in
         try:
             res = self._guard(npts, calccov, prefetch, params, infos, Coeffs, Cov, chi, ranks, cov_rows, stamp)
-        finally:
-            self.join_cov()
+        except BaseException as guard_exc:
+            # the download thread is joined either way, but the guard's own failure is the one the caller must see: a failure
+            # of the thread on top of it travels as its context, not in its place
+            try:
+                self.join_cov()
+            except BaseException as down_exc:
+                raise guard_exc from down_exc
+            raise
+        self.join_cov()
         for t, row in cov_rows:
             Cov[t] = row
         return res

@@ -224,10 +224,13 @@ class Model(DeviceModel):
         return eval_omega(self)
 
     def eval_psi(self):
-        # Gauss quadrature (regmat.eval_psi_gauss: exact z-integral, analytic phi-integral) unless the QUADPACK restatement
-        # of the reference is asked for (VINTERP_REGMAT=quad: bit-identical to the reference's Psi, a thousand times slower)
+        # The reference's own values by default (regmat.eval_psi: its integrands and quad calls, each distinct 1-D integral
+        # once - bit-identical to sphharmlag.py:215-239, 2.4 s at N = 144).  VINTERP_REGMAT=gauss: exact quadrature
+        # (regmat.eval_psi_gauss: milliseconds; 5e-10 of max|Psi| away from the QUADPACK values, which moves the fitted
+        # coefficients of tests/golden/fit_k8l2_psi.npz by less than 1e-6 - tests/test_gpu_fit.py - but a default must give
+        # the reference's numbers).
         import os
         from ..regmat import eval_psi, eval_psi_gauss
-        if os.environ.get('VINTERP_REGMAT', 'gauss') == 'quad':
-            return eval_psi(self)
-        return eval_psi_gauss(self)
+        if os.environ.get('VINTERP_REGMAT', 'quad') == 'gauss':
+            return eval_psi_gauss(self)
+        return eval_psi(self)

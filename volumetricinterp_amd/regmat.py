@@ -79,7 +79,7 @@ def eval_psi_gauss(model, ntheta=None):
     The three factors of psi_ij are convergent and smooth (unlike Omega's z-integral, which diverges - SURVEY F5 - so that
     the reference's Omega is a QUADPACK artefact no other quadrature can reproduce):
       z      int_0^inf e^-z L_ki L_kj z^2 dz   - a polynomial of degree <= 2 maxk against e^-z: Gauss-Laguerre with maxk + 2
-             nodes is exact (finite MAX_Z_INT: Gauss-Legendre on [0, MAX_Z_INT]);
+             nodes is exact (finite MAX_Z_INT: the reference's adaptive quad call, once per (ki, kj));
       theta  int_0^cap P_vi^mi(cos t) P_vj^mj(cos t) sin t dt  - Gauss-Legendre on [0, cap], nodes growing with the degree;
       phi    int_0^2pi Az_i Az_j dphi = Kvm_i Kvm_j x (2 pi | pi | 0)  - analytic.
     One table per factor, the matrix is their outer combination: milliseconds at N = 144 (2.4 s with the de-duplicated
@@ -94,12 +94,17 @@ def eval_psi_gauss(model, ntheta=None):
     if np.isinf(model.max_z_int):
         zx, zw = np.polynomial.laguerre.laggauss(maxk + 2)
         zw = zw * zx**2
+        Lk = np.array([sp.eval_laguerre(k, zx) for k in range(maxk)])
+        Iz = (Lk * zw) @ Lk.T
     else:
-        gx, gw = np.polynomial.legendre.leggauss(max(64, 4 * maxk))
-        zx = 0.5 * model.max_z_int * (gx + 1.)
-        zw = 0.5 * model.max_z_int * gw * np.exp(-zx) * zx**2
-    Lk = np.array([sp.eval_laguerre(k, zx) for k in range(maxk)])
-    Iz = (Lk * zw) @ Lk.T
+        # finite limit: e^-z z^2 L_ki L_kj on [0, Z] is no polynomial weight any more and a fixed Gauss-Legendre rule is only
+        # converged while Z is small against its node count (a limit of 1e3 used as 'practically infinite' is not).  There
+        # are only maxk (maxk + 1) / 2 such integrals: the reference's own adaptive quad call for each (sphharmlag.py:230).
+        Iz = np.zeros((maxk, maxk))
+        for ki in range(maxk):
+            for kj in range(ki, maxk):
+                Iz[ki, kj] = Iz[kj, ki] = scipy.integrate.quad(
+                    lambda z: np.exp(-1 * z) * sp.eval_laguerre(ki, z) * sp.eval_laguerre(kj, z) * z**2, 0., model.max_z_int)[0]
     Iz = 0.5 * (Iz + Iz.T)                      # the products round asymmetrically; the reference fills Psi symmetrically
     # theta: signed order into lpmv, as the reference does
     if ntheta is None:
