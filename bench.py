@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the fit + evaluate hot path on MI355X.
 
-Workload "c1" (default at N = 1; BASELINE.json configs[1], the configuration the metric is quoted on): a "step" is one
-pass of the hot path over one batch of synthetic input - fit ONE record (26 beams x 100 ranges, default order MAXK=4
-MAXL=6 -> N=144, curvature regularisation, chi^2 search, covariance) and evaluate the fitted model on a 128^3 geodetic
-query grid with the convex-hull mask on (the reference's default check_hull=True).  Step t fits record t mod 16 of
-sixteen distinct resident records: the number of root-finder iterations (12-60, decided by where chi^2(alpha) jumps)
-differs from record to record, so the line reports the mean over the records together with median / min / max and
-the verdicts of the engine's consistency guard.
-Workload "c3" (default at N > 1; BASELINE.json configs[3]): 10000 timesteps of that geometry sharded ceil(T/N) per rank -
-independent records, no data-path collective -, each rank fits its shard as one batch and evaluates EVERY timestep of it
-on a 256^3 grid (basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call), all of it
-inside the timed region; strong scaling, value = timesteps/s over the barrier-to-barrier wall time, max over ranks.
+ONE workload at every N (round 4; VERDICT round 3: the N = 1 and the N > 1 lines used to be different workloads, so no scaling
+curve could be formed): **workload c3 = BASELINE.json configs[3]** - 10000 timesteps (26 beams x 100 ranges, default order
+MAXK=4 MAXL=6 -> N=144, curvature regularisation, chi^2 search, covariance) sharded ceil(T/N) per rank - independent records, no
+data-path collective -, each rank fits its shard as one batch and evaluates EVERY timestep of it on a 256^3 geodetic grid with
+the hull mask (basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call), all of it inside
+the timed region.  A "step" is one such pass; strong scaling; value = timesteps/s = T / (barrier-to-barrier wall time per
+step, max over ranks).  The line carries
+  roofline       the dominant part of the step, the FIT: the in-LDS eigen-solves K3 (k_jacobi_solve launches + the Jacobi rounds
+                 inside k_brent_warm), algorithmic LDS bytes counted by the kernels themselves over HIP-event launch durations;
+  roofline_eval  the evaluation product K2r against the fp64 matrix peak;
+  cpu_baseline   (N = 1) the oracle - the faithful CPU restatement of the reference - on 16 records + a hull-masked sub-grid,
+                 extrapolated to timesteps/s;
+and, at N = 1, secondary objects that are NOT part of `value`: `single_record` (BASELINE configs[1], the latency path: one
+record + 128^3 grid per step, mean / median / max over sixteen distinct records, with the K3 launch figures of that path),
+`roofline_eval_fused` (the fused evaluation kernel with and without the hull pass), `eval_many_timesteps`, `batched_records`
+(configs[2]: 1000 records in one batch).
+`--workload c1` prints the configs[1] line on its own (weak-scaling replica per rank), as rounds 1-3 did at N = 1.
 Inputs (beam geometry, weights/data, query grid, regularisation matrix, hull facets) are resident in HBM before the
 timed region; outputs stay on the device.  Shared parameters are broadcast once from rank 0 over RCCL before the timed
 region; if RCCL was to be used and did not come up, the line says so and the exit status is 3.
@@ -51,25 +57,27 @@ LDS_RW_BYTES_PER_CLK_CU = 2. / (1. / 256. + 1. / 85.)
 LDS_PEAK_GBS = LDS_RW_BYTES_PER_CLK_CU * CLOCK_GHZ * N_CU          # ~78 TB/s, all 256 CUs streaming
 EVAL_BYTES_PER_POINT = 32.0    # 3 x 8 B coordinates in + 8 B density out
 EVAL_FLOPS_PER_POINT = 3.0e3   # SURVEY 8d E1 estimate at the default order
+# K2r, one call of 256 timesteps on 256^3 points: HBM bytes read + written from the PMC passes of profiles/r3_k2r_pmc.txt
+K2R_PMC_BYTES_PER_256_TIMESTEPS = 30.2e9 + 34.4e9
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='default: 16 (workload c1), 2 (workload c3)')
+    ap.add_argument('--steps', type=int, default=None, help='default: 2 (workload c3), 16 (workload c1)')
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', choices=('c1', 'c3'), default=None,
-                    help="c1: BASELINE configs[1], one record + 128^3 grid per step and GPU (default at N = 1); "
-                         "c3: configs[3], 10000 timesteps sharded over the ranks, 256^3 grid (default at N > 1)")
+    ap.add_argument('--workload', choices=('c1', 'c3'), default='c3',
+                    help="c3 (default at every N): BASELINE configs[3], 10000 timesteps sharded over the ranks, 256^3 grid; "
+                         "c1: configs[1] on its own, one record + 128^3 grid per step and GPU (weak-scaling replica)")
     ap.add_argument('--records', type=int, default=10000, help='timesteps of workload c3 (all ranks together)')
-    ap.add_argument('--grid', type=int, default=128, help='query grid edge (128 -> 128^3 points)')
+    ap.add_argument('--grid', type=int, default=128, help='query grid edge of the configs[1] figures (128 -> 128^3 points)')
+    ap.add_argument('--c3-grid', type=int, default=256, help='query grid edge of workload c3 (rehearsals: smaller)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='workload c3 at N = 1: skip the secondary objects')
     ap.add_argument('--no-eval-many', action='store_true', help='skip the secondary many-timesteps evaluation figure')
     ap.add_argument('--no-batched', action='store_true', help='skip the secondary batched-records figure (configs[2])')
     ap.add_argument('--batched-records', type=int, default=1000, help='records of the configs[2] figure')
     args = ap.parse_args()
-    if args.workload is None:
-        args.workload = 'c1' if args.gpus <= 1 else 'c3'
     if args.steps is None:
         args.steps = 16 if args.workload == 'c1' else 2
     return args
@@ -148,11 +156,13 @@ def _cpu_worker(job):
     return dict(t_fit=t_fit, t_eval=t_eval, t_eval_nohull=t_eval_nohull, eval_C_calls=counter[0] + 1)
 
 
-def cpu_baseline(grid_n):
+def cpu_baseline(grid_n, unit='points/s'):
     """The oracle (faithful CPU restatement of the reference, kind 'port') on a bounded sample of the same workload,
-    as BASELINE.md section 4 asks: one process, then `multiprocessing` over independent records on all host cores; plus
-    the optimised-CPU variant for context.  Sample per worker: the full one-record fit (26 x 100, N = 144) and a
-    hull-masked evaluation of a 12^3 sub-grid scaled to grid_n^3 points."""
+    as BASELINE.md section 4 asks: one process, then `multiprocessing` over independent records on the box's host-core share;
+    plus the optimised-CPU variant for context.  Sample per worker: the full one-record fit (26 x 100, N = 144) and a
+    hull-masked evaluation of a 12^3 sub-grid scaled to grid_n^3 points.  unit 'timesteps/s' (workload c3): a timestep = that
+    fit + that evaluation, records being independent the rate of W workers is the sum of their own rates; 'points/s'
+    (workload c1): the same time per timestep, counted in evaluated points."""
     import multiprocessing as mp
     sub = 12
     Q = grid_n**3
@@ -166,7 +176,7 @@ def cpu_baseline(grid_n):
     ctxmp = mp.get_context('spawn')                 # fresh interpreters: nothing of the GPU runtime is inherited
 
     def rate(r):
-        return Q / (r['t_fit'] + r['t_eval'] * Q / sub**3)
+        return (Q if unit == 'points/s' else 1.) / (r['t_fit'] + r['t_eval'] * Q / sub**3)
     # (map_async + a deadline: a worker that dies - it happened once under a profiler's preloaded tool - would leave
     # pool.map waiting for ever; the bench then reports the baseline as missing instead of hanging)
     with ctxmp.Pool(1) as pool:
@@ -177,13 +187,15 @@ def cpu_baseline(grid_n):
         many = pool.map_async(_cpu_worker, [(1000 + i, sub, 'faithful') for i in range(workers)], chunksize=1).get(timeout=480)
     wall = time.perf_counter() - t0
     all_rate = sum(rate(r) for r in many)           # every worker's own step rate under full load
-    return dict(value=all_rate, unit='points/s', cores=workers, kind='port',
-                sample='oracle (NumPy/SciPy restatement of the reference, one BLAS thread per process): %d processes, '
-                       'each the full fit of one 26x100 record at N=144 (%d eval_C calls, %.1f s alone, %.1f s mean under '
-                       'load) + a hull-masked (one Qhull per point) evaluation of a %d^3 sub-grid (%.2f s) scaled to '
-                       '%d^3 points; wall %.1f s'
-                       % (workers, one['eval_C_calls'], one['t_fit'], float(np.mean([r['t_fit'] for r in many])), sub,
-                          one['t_eval'], grid_n, wall),
+    return dict(value=all_rate, unit=unit, cores=workers, kind='port',
+                sample='oracle (NumPy/SciPy restatement of the reference, one BLAS thread per process): %d processes = %d '
+                       'records, each the full fit of one 26x100 record at N=144 (%d eval_C calls, %.1f s alone, %.1f s mean '
+                       'under load) + a hull-masked (one Qhull per point) evaluation of a %d^3 sub-grid (%.2f s) scaled to '
+                       '%d^3 points (%.0f s per timestep); value = sum over the processes of 1 / (their own time per timestep)'
+                       '%s; wall %.1f s'
+                       % (workers, workers, one['eval_C_calls'], one['t_fit'], float(np.mean([r['t_fit'] for r in many])), sub,
+                          one['t_eval'], grid_n, float(np.mean([r['t_fit'] + r['t_eval'] * Q / sub**3 for r in many])),
+                          ' x points per timestep' if unit == 'points/s' else '', wall),
                 host_cpu_count=ncpu, host_cpus_available=ncpu_avail, cpu_model=_cpu_model(), blas_threads_per_process=1,
                 single_process={'value': rate(one), 'cores': 1, 'fit_seconds': one['t_fit'],
                                 'eval_points_per_sec': sub**3 / one['t_eval'],
@@ -193,8 +205,10 @@ def cpu_baseline(grid_n):
                                           'eval_C_calls': fast['eval_C_calls'],
                                           'note': 'A^T W A once per record, chi^2(alpha) memoised across scale factors; '
                                                   'same LAPACK calls on the same matrices (context only)'},
-                all_cores={'timesteps_per_sec': workers / float(np.mean([r['t_fit'] for r in many])),
-                           'fit_seconds_mean': float(np.mean([r['t_fit'] for r in many]))})
+                core_share={'processes': workers, 'fit_timesteps_per_sec': workers / float(np.mean([r['t_fit'] for r in many])),
+                            'fit_seconds_mean': float(np.mean([r['t_fit'] for r in many])),
+                            'note': 'fit only (no evaluation), all processes together; the processes are the 16-core share '
+                                    'a one-GPU job gets of the host, not all %d hardware threads' % ncpu})
 
 
 def main():
@@ -220,9 +234,10 @@ def run(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args.grid)
+            cpu = cpu_baseline(args.grid, 'points/s') if args.workload == 'c1' else cpu_baseline(args.c3_grid, 'timesteps/s')
         except Exception as e:                       # a timed-out or dead worker: say so in the line, do not hang or die
-            cpu = dict(value=None, unit='points/s', cores=0, kind='port', sample='not measured: %s: %s' % (type(e).__name__, e))
+            cpu = dict(value=None, unit='points/s' if args.workload == 'c1' else 'timesteps/s', cores=0, kind='port',
+                       sample='not measured: %s: %s' % (type(e).__name__, e))
 
     from volumetricinterp_amd import _lib, synth
     from volumetricinterp_amd.estimate import hull_equations
@@ -262,10 +277,42 @@ def run(args):
     A = At.download().T
     if args.workload == 'c3':
         out = run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world)
+        if rank == 0 and world == 1:
+            out['cpu_baseline'] = cpu
+            if not args.no_secondary:
+                # secondary objects (not part of `value`): the single-record latency path of configs[1] and the evaluation
+                # kernels on their own, measured after the timed region of workload c3
+                c1 = run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, steps=16, warmup=1)
+                out['single_record'] = {
+                    'workload': c1['config']['workload'], 'points_per_sec': c1['value'], 'ms_per_step': c1['ms_per_step'],
+                    'steps': c1['steps'], 'step_ms': c1['step_ms'], 'guard_verdicts': c1['guard_verdicts'],
+                    'breakdown_ms': c1['breakdown_ms'], 'steps_detail': c1['steps_detail'], 'roofline': c1.get('roofline')}
+                out['roofline_eval_fused'] = c1['roofline_eval']
+                for k in ('eval_many_timesteps', 'batched_records'):
+                    if k in c1:
+                        out[k] = c1[k]
         if rank == 0:
             real_stdout.write(json.dumps(out) + '\n')
             real_stdout.flush()
         return finish(comm, world)
+    out = run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, steps=args.steps, warmup=args.warmup)
+    if rank == 0:
+        if world == 1:
+            out['cpu_baseline'] = cpu
+        real_stdout.write(json.dumps(out) + '\n')
+        real_stdout.flush()
+    return finish(comm, world)
+
+
+def run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, steps, warmup):
+    """BASELINE configs[1], the single-record latency path: a step = fit ONE record (26 x 100, N = 144, curvature, chi^2
+    search, covariance) + evaluate it on a 128^3 grid with the hull mask; step t fits record t mod 16 of sixteen distinct
+    resident records.  Returns the line of `--workload c1` (rank 0; None elsewhere); workload c3 at N = 1 embeds parts of it
+    as secondary objects."""
+    from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    N, P = model.nbasis, A.shape[0]
+    F = hull_eq.shape[0]
     T = 1
     # Sixteen distinct synthetic records, each resident in its own engine (one record per step: the single-record latency
     # path); the engines share their scratch buffers.  Every rank fits the same records: weak scaling means identical
@@ -343,17 +390,17 @@ def run(args):
         ctx.sync()
         comm.barrier()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     ctx.solve_timing(1)            # one HIP event pair around every eigen-solve kernel launch of the timed steps
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         res = step(i, record=True)
     barrier()
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     st = ctx.solve_timing(0)
-    solves_per_step = sum(e_.stats['solves'] for e_ in engs) / max(1, args.steps + args.warmup)
+    solves_per_step = sum(e_.stats['solves'] for e_ in engs) / max(1, steps + warmup)
 
     def kernel_ms(fn, reps=5):
         best = float('inf')
@@ -474,17 +521,17 @@ def run(args):
                 traffic_eval = pmc['hbm_bytes_per_launch']
         except Exception:
             pass
-        pts = args.steps * Q * T * world
+        pts = steps * Q * T * world
         out = {
             'metric': 'fit+eval query-points/sec', 'value': pts / elapsed, 'unit': 'points/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: per GPU and step 1 record (step t fits record t mod %d of %d distinct resident '
                                    'records), 26-beam x 100-range fit (N=144, curvature, chi2 search, covariance) + %d^3 '
                                    'geodetic query grid with the hull mask, fp64' % (NREC, NREC, args.grid),
                        'points_per_step_per_gpu': Q * T, 'timesteps_per_step_per_gpu': T, 'distinct_records': NREC},
-            'timesteps_per_sec': args.steps * T * world / elapsed,
+            'timesteps_per_sec': steps * T * world / elapsed,
             'step_ms': {'mean': float(np.mean(step_ms)), 'median': float(np.median(step_ms)), 'min': float(np.min(step_ms)),
                         'max': float(np.max(step_ms)), 'note': 'rank 0, per step (host clock around fit + evaluation); '
                                                                'ms_per_step is the mean over the timed steps'},
@@ -503,7 +550,7 @@ def run(args):
         #      counted by the kernel itself; durations are HIP events around every launch of the timed steps.
         if st['timed']:
             avg_ms = st['total_ms'] / st['timed']
-            launches_per_step = st['launches'] / args.steps
+            launches_per_step = st['launches'] / steps
             lds_bytes_per_launch = 2. * 8. * (N * (N + 1) // 2) * st['rounds'] / max(1, st['launches'])
             flops_per_launch = 10. * N**3 * st['systems'] / max(1, st['launches'])
             ach = lds_bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -515,7 +562,7 @@ def run(args):
                                 'back, against ~0.1-0.5 GB through LDS',
                 'launches_per_step': launches_per_step, 'systems_per_launch': sys_per_launch,
                 'avg_launch_ms': avg_ms, 'max_launch_ms': st['max_ms'], 'ms_per_step': avg_ms * launches_per_step,
-                'share_of_step': avg_ms * launches_per_step / (elapsed / args.steps * 1e3),
+                'share_of_step': avg_ms * launches_per_step / (elapsed / steps * 1e3),
                 'rounds_per_system': st['rounds'] / max(1, st['systems']),
                 'peak_note': 'chip-wide LDS rate for equal read and write volumes: %.0f B/clk/CU x %.1f GHz x %d CUs; one '
                              'system occupies one CU, so a launch of B systems can reach at most min(B,256)/256 of it'
@@ -542,11 +589,10 @@ def run(args):
             out['eval_many_timesteps'] = many
         if batched is not None:
             out['batched_records'] = batched
-        if world == 1:
-            out['cpu_baseline'] = cpu
-        real_stdout.write(json.dumps(out) + '\n')
-        real_stdout.flush()
-    return finish(comm, world)
+        for b_ in dq + [dhull, dC, dout]:
+            b_.free()
+        return out
+    return None
 
 
 def finish(comm, world):
@@ -582,7 +628,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     value, error = synth.synth_records(A, share, seed0=1000 + lo) if share else (np.zeros((0, P)), np.ones((0, P)))
     eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
     eng.upload_records(error**-2., value)
-    n = 256
+    n = int(args.c3_grid)
     g = synth.query_grid(n)
     Q = g[0].size
     dq = [ctx.to_device(a.ravel()) for a in g]
@@ -629,6 +675,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
 
     for _ in range(args.warmup):
         step()
+    eng.solve_timing(1)             # one HIP event pair around every eigen-solve launch of the timed steps, on its own stream
     ctx.sync()
     comm.barrier()
     t0 = time.perf_counter()
@@ -637,14 +684,60 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     ctx.sync()
     comm.barrier()
     wall = comm.max_over_ranks(time.perf_counter() - t0)
+    st = eng.solve_timing(0)
+    pipelines = eng.stats.get('pipelines', 1)
     # per rank: the measured time of a step - fit of the shard + basis of the grid + evaluation of every timestep of the shard
     mine = float(np.mean(step_s_list)) if share else 0.
     per_rank = [float(np.frombuffer(b_, dtype=np.float64)[0]) for b_ in comm.allgather_bytes(np.array([mine]).tobytes())]
     fits = [float(np.frombuffer(b_, dtype=np.float64)[0])
             for b_ in comm.allgather_bytes(np.array([float(np.mean(fit_s)) if fit_s else 0.]).tobytes())]
     step_s = wall / args.steps            # barrier to barrier, max over ranks: nothing scaled
+    # free what the secondary legs of an N = 1 run do not need (the basis matrix of the grid alone is 19 GB)
+    for b_ in dq + [dhull, dC, dout] + ([dY] if dY is not None else []):
+        b_.free()
+    eng.close()
     if rank != 0:
         return None
+    # ---- roofline of the dominant part of the step, the FIT (rank 0's shard): the in-LDS eigen-solves K3 - every
+    #      k_jacobi_solve launch and the Jacobi rounds inside the k_brent_warm launches (one per pipeline and step: Brent's
+    #      iteration of its records, whose whole duration is counted, chi^2 and re-basing included).  Neither HBM nor MFMA
+    #      bound them: a system lives in one CU's LDS and every round moves it once through the registers.  Algorithmic
+    #      bytes: 2 (read + write) x 8 B x N(N+1)/2 per round and system, rounds counted by the kernels
+    #      themselves; algorithmic flops: 12 per stored element and round (two row and two column rotations of 3 flops).
+    fit_roof = None
+    if st['timed'] and fit_s:
+        fit_wall = float(np.mean(fit_s))
+        rounds_step = st['rounds'] / args.steps
+        launches_step = st['launches'] / args.steps
+        avg_ms = st['total_ms'] / st['timed']
+        k3_ms_step = avg_ms * launches_step                       # summed over the pipelines' streams (their launches overlap)
+        busy_s = min(k3_ms_step * 1e-3, fit_wall)
+        lds_bytes_step = 2. * 8. * (N * (N + 1) // 2) * rounds_step
+        flops_step = 12. * (N * (N + 1) // 2) * rounds_step
+        ach = lds_bytes_step / busy_s / 1e9
+        fit_roof = {
+            'kernel': 'K3: k_jacobi_solve launches + the Jacobi rounds inside k_brent_warm (in-LDS eigen-solves of the fit)',
+            'bound': 'lds', 'achieved': ach, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / LDS_PEAK_GBS, 'traffic': None,
+            'traffic_note': 'HBM traffic is not the resource: per system 166 KB in, ~1.3 MB of rotation log out and back, '
+                            'against ~0.1-0.5 GB through LDS',
+            'definition': 'algorithmic LDS bytes of all K3 rounds of a step / the time K3 kernels were running in that step = '
+                          'min(sum of the launch durations over the %d concurrent pipelines, wall time of the fit)' % pipelines,
+            'lds_bytes_per_step': lds_bytes_step, 'rounds_per_step': rounds_step, 'systems_per_step': st['systems'] / args.steps,
+            'launches_per_step': launches_step, 'avg_launch_ms': avg_ms, 'max_launch_ms': st['max_ms'],
+            'launch_ms_summed_per_step': k3_ms_step, 'fit_wall_ms_per_step': fit_wall * 1e3,
+            'share_of_step': fit_wall / step_s,
+            'per_launch': {'achieved': lds_bytes_step / max(1e-12, k3_ms_step * 1e-3) / 1e9, 'unit': 'GB/s',
+                           'note': 'algorithmic bytes per launch / average launch duration (HIP events on the launching '
+                                   'stream) - the figure a rocprofv3 kernel trace reproduces; concurrent launches share the '
+                                   'chip, so it understates the chip-wide rate by up to the number of pipelines'},
+            'peak_note': 'chip-wide LDS rate for equal read and write volumes: %.0f B/clk/CU x %.1f GHz x %d CUs; one system '
+                         'occupies one CU' % (LDS_RW_BYTES_PER_CLK_CU, CLOCK_GHZ, N_CU),
+            'fp64': {'achieved_tflops': flops_step / busy_s / 1e12, 'peak_tflops': FP64_PEAK_TF,
+                     'frac': flops_step / busy_s / 1e12 / FP64_PEAK_TF,
+                     'flops_model': '12 flop per stored element and round, counted rounds (a converged cold solve of 10 sweeps is '
+                                    '~30 N^3; SURVEY 8d F2 quotes ~10 N^3 per solve)'},
+            'records_per_sec_fit': share / fit_wall}
+    k2r_traffic = K2R_PMC_BYTES_PER_256_TIMESTEPS if (resident and Q == 256**3 and TILE == 256) else None
     return {
         'metric': 'fit+eval timesteps/sec', 'value': Ttot / step_s, 'unit': 'timesteps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
@@ -667,13 +760,19 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
                   'eval_point_timesteps_per_sec': (share * Q / (float(np.mean(eval_ms)) * 1e-3)) if eval_ms and share else None,
                   'records_per_sec_fit': share / float(np.mean(fit_s)) if fit_s else None,
                   'outcomes': {o_: outcomes.count(o_) for o_ in set(outcomes)} if outcomes else None,
-                  'pipelines': eng.stats.get('pipelines', 1)},
-        'roofline': {'kernel': ('k_eval_resident (K2r: v_mfma_f64_16x16x4 on the resident basis)' if resident else 'k_eval_sph_mfma')
-                               + ' (evaluation tile; the fit side is the k_jacobi_solve line of workload c1)',
-                     'bound': 'mfma', 'achieved': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12) if eval_ms and share else None,
-                     'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',
-                     'frac': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12 / FP64_PEAK_TF) if eval_ms and share else None,
-                     'traffic': None},
+                  'pipelines': pipelines},
+        'roofline': fit_roof,
+        'roofline_eval': {
+            'kernel': ('k_eval_resident (K2r: v_mfma_f64_16x16x4 on the basis matrix of the grid resident in HBM)' if resident
+                       else 'k_eval_sph_mfma'),
+            'bound': 'mfma', 'achieved': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12) if eval_ms and share else None,
+            'peak': FP64_PEAK_TF, 'unit': 'TFLOP/s',
+            'frac': (2. * N * share * Q / (float(np.mean(eval_ms)) * 1e-3) / 1e12 / FP64_PEAK_TF) if eval_ms and share else None,
+            'ms_per_step': float(np.mean(eval_ms)) if eval_ms else None,
+            'share_of_step': (float(np.mean(eval_ms)) * 1e-3 / step_s) if eval_ms else None,
+            'flops_model': '2 N flop per point-timestep (SURVEY 8d E2)', 'traffic': k2r_traffic,
+            'traffic_note': 'HBM bytes per call of 256 timesteps on 256^3 points from the committed PMC passes '
+                            '(profiles/r3_k2r_pmc.txt: read + written), algorithmic 53.7 GB'},
         'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
     }
 
