@@ -4,7 +4,8 @@ configs[0] (11 x 50, default order, plumbing) and the evaluation leg of configs[
 test_gpu_dropin.py / test_gpu_default_order.py / test_gpu_properties.py; this file adds
   configs[1]  the FIT leg at 26 x 100, N = 144: normal equations, one solve, batch independence, chi^2 consistency;
   configs[2]  1000 records of one geometry in one batch;
-  configs[3]  a 256^3 query grid shared by 64 timesteps (the matrix-core evaluation kernel);
+  configs[3]  a 256^3 query grid shared by 64 timesteps (the matrix-core evaluation kernel), and one rank's share of the
+              config at its own size: 1250 records in one batch + the resident-basis evaluation (K2r) on 256^3;
   configs[4]  the doubled order MAXK 8, MAXL 12 (N = 1152) on 64 x 200 points: basis, normal equations, one solve, and
               the whole fit end to end (chi^2 search + final solve with covariance on the rocSOLVER path).
 Sizes the CPU oracle cannot reach in seconds are checked stage by stage against NumPy / SciPy on the same inputs and
@@ -389,6 +390,98 @@ def test_c3_256cubed_64_timesteps_on_device():
     _lib.check(_lib.lib.vi_d2h(ctx.handle, b.ctypes.data_as(_lib.VOIDP), d2.offset_ptr(17 * Qh + 1000), b.nbytes), 'd2h')
     assert np.array_equal(b, rows(dout, 17, Qh + 1000, S))
     for x in (dout, d1, d2, dC, *dq):
+        x.free()
+
+
+def test_c3_shard_at_its_own_size():
+    """BASELINE configs[3] as `bench.py` runs it on one rank of eight (until now only bench.py's clock
+    covered this path at its own size): the 1250-record shard fitted as ONE batch, and its timesteps evaluated on the 256^3 grid
+    (Q = 2^24, hull mask on) by the RESIDENT-basis path - vi_eval_basis_f64 once, then vi_eval_resident_f64 (K2r) per tile of
+    timesteps: 333 of them as a full tile of 256 and a ragged one of 77 = 64 + 13, i.e. `groups = 32` point groups per
+    workgroup, 10^4 workgroups through the XCD-aware block order, the ragged last timestep tile.
+      * three records of the shard re-fitted alone: alpha, chi^2, coefficients BIT FOR BIT (interpolate.py:511-579 - records
+        carry no state);
+      * rows 0, 255 (first tile), 256, 332 (ragged tile) against the fused kernel vi_eval_f64 on three windows of 2^20 points:
+        <= 1e-12, NaN (hull) mask identical;
+      * against the CPU oracle (estimate.py:110-123, :153-178) on 4096 sampled points: <= 1e-10 (gate L6), mask identical."""
+    import oracle
+    from scipy.spatial import ConvexHull
+    from volumetricinterp_amd import _lib, synth
+    from volumetricinterp_amd.estimate import hull_equations
+    from volumetricinterp_amd.geodesy import geodetic2ecef
+    m, ctx, eng, A, (lat, lon, alt) = _engine(CFG144, synth.GEOM_C2)
+    h = m.handle(ctx)
+    P, T, N = A.shape[0], 1250, 144
+    value, error = synth.synth_records(A, T, seed0=1000)              # rank 0's shard of bench.py's workload c3
+    W = error**-2.
+    res = eng.fit(W, value, [P] * T)
+    oc = res['search']['curvature']['outcomes']
+    roots = [t for t in range(T) if oc[t] == 'root']
+    assert len(roots) >= 1000
+    assert np.all(np.isnan(res['Coeffs'][[t for t in range(T) if oc[t] == 'no_root']]))
+    for t in (roots[0], roots[len(roots) // 2], roots[-1]):
+        one = eng.fit(W[t:t + 1], value[t:t + 1], [P])
+        assert one['reg_params'][0]['curvature'] == res['reg_params'][t]['curvature'], t
+        assert one['chi_sq'][0] == res['chi_sq'][t]
+        assert np.array_equal(one['Coeffs'][0], res['Coeffs'][t]), t
+    eng.close()
+
+    # ---- evaluation of the shard's first 333 timesteps on 256^3 from the resident basis
+    TE, TILE, n = 333, 256, 256
+    Q = n**3
+    C = np.nan_to_num(res['Coeffs'][:TE])                              # NaN rows (no root) evaluate as zeros, as in bench.py
+    g = [np.ascontiguousarray(a.ravel()) for a in synth.query_grid(n)]
+    hull_vert = np.array(geodetic2ecef(lat, lon, alt)).T
+    hull_vert = hull_vert[ConvexHull(hull_vert).vertices]
+    eq, tol = hull_equations(hull_vert)
+    F = eq.shape[0]
+    dq = [ctx.to_device(a) for a in g]
+    dhull, dC = ctx.to_device(eq), ctx.to_device(C)
+    dY = ctx.empty((N, Q))                                             # 19.3 GB
+    dout = ctx.empty((TILE, Q))                                        # 34 GB: one tile of densities, as in bench.py
+    _lib.check(_lib.lib.vi_eval_basis_f64(h, Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, dhull.ptr, F, tol, dY.ptr), 'vi_eval_basis_f64')
+
+    def row(darr, r, stride):
+        out = np.empty(Q)
+        _lib.check(_lib.lib.vi_d2h(ctx.handle, out.ctypes.data_as(_lib.VOIDP), darr.offset_ptr(r * stride), out.nbytes), 'd2h')
+        return out
+    got = {}
+    for s0 in range(0, TE, TILE):
+        tl = min(TILE, TE - s0)
+        _lib.check(_lib.lib.vi_eval_resident_f64(h, Q, tl, dY.ptr, dC.offset_ptr(s0 * N), dout.ptr), 'vi_eval_resident_f64')
+        for t in ((0, 255) if s0 == 0 else (256, 332)):
+            got[t] = row(dout, t - s0, Q)
+    dY.free()
+    dout.free()
+    ts = sorted(got)
+    assert roots[0] in range(TE) and all(np.any(C[t] != 0.) for t in ts)
+    # the fused kernel on three windows of 2^20 points, the four rows as one call
+    S = 1 << 20
+    d4, dw = ctx.to_device(C[ts]), ctx.empty((len(ts), S))
+    inside_total = 0
+    for lo in (0, Q // 2 - 12345, Q - S):
+        _lib.check(_lib.lib.vi_eval_f64(h, S, dq[0].offset_ptr(lo), dq[1].offset_ptr(lo), dq[2].offset_ptr(lo), len(ts), d4.ptr,
+                                        dhull.ptr, F, tol, dw.ptr), 'vi_eval_f64')
+        fused = dw.download()
+        for k, t in enumerate(ts):
+            mine = got[t][lo:lo + S]
+            assert np.array_equal(np.isnan(mine), np.isnan(fused[k])), (t, lo)
+            ok = np.isfinite(mine)
+            inside_total += int(ok.sum())
+            if ok.any():
+                assert rel(mine[ok], fused[k][ok]) <= 1e-12, (t, lo)
+    assert inside_total > 100000                                       # the middle window lies inside the hull
+    # the CPU oracle on 4096 sampled points
+    idx = np.sort(np.random.default_rng(33).choice(Q, 4096, replace=False))
+    o = oracle.SphHarmLagOracle()
+    Ao = o.basis(g[0][idx], g[1][idx], g[2][idx])
+    chk = oracle.check_hull(hull_vert, g[0][idx], g[1][idx], g[2][idx])
+    assert 200 < chk.sum() < 3900
+    for t in ts:
+        mine = got[t][idx]
+        assert np.array_equal(np.isfinite(mine), chk), t
+        assert rel(mine[chk], (Ao @ C[t])[chk]) <= 1e-10, t
+    for x in (d4, dw, dhull, dC, *dq):
         x.free()
 
 
