@@ -29,7 +29,8 @@ extern "C" {
 #endif
 
 /* 2 (round 4): vi_warm_solve_f64 / vi_basis_solve_f64 / vi_warm_rebase_f64 take a trailing d_sweeps pointer,
- * vi_warm_chi2_one_f64 writes THREE doubles to h_chi2, vi_brent_warm_supported added.  _lib.py refuses any other version. */
+ * vi_warm_chi2_one_f64 writes THREE doubles to h_chi2, vi_brent_warm_supported added, h_rebase of vi_brent_warm_f64 /
+ * vi_brent_host_one_f64 is 10 doubles (jump rule).  _lib.py refuses any other version. */
 #define VI_ABI_VERSION 2
 
 typedef enum vi_status {
@@ -287,9 +288,12 @@ int  vi_warm_chi2_one_f64(vi_ctx* ctx, int32_t N, int64_t P, const double* d_D1,
  * was ended by the sweep cap (run that record's iteration on the host), 3 = more than 100 iterations.  Bit for bit the
  * result of the host-driven iteration from the same rotated system.
  * The rotated systems (d_D1, d_D2, d_yt, d_V, by slot) are MOVED next to the root as the host path does
- * (vi_warm_rebase_f64) by the rule in h_rebase (host, 8 doubles: number of thresholds, up to four thresholds in decades
- * between consecutive abscissae, then the late move: after so many requests, within so many decades, enabled) - from
- * d_AWA, d_y (by record) and d_R. */
+ * (vi_warm_rebase_f64) by the rule in h_rebase (host, 10 doubles: number of thresholds, up to four thresholds in decades
+ * between consecutive abscissae, then the late move: after so many requests, within so many decades, enabled; then the early
+ * end on a JUMP of chi^2(alpha) - a sign change without a root, where an eigenvalue of X(alpha) crosses the truncation cut,
+ * which brentq bisects to 2e-12 in 40-60 values: [8] width in decades of log10 alpha, [9] fraction of nu - the iteration ends
+ * once the bracket is narrower than the width while both ends miss nu by more than that fraction; zeros: brentq's own end)
+ * - from d_AWA, d_y (by record) and d_R. */
 int  vi_brent_warm_f64(vi_ctx* ctx, int64_t ntask, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt,
                        double* d_V, const double* d_AWA, const double* d_R, const double* d_y, const double* h_rebase,
                        const double* d_At, const double* d_W, const double* d_b,

@@ -409,6 +409,56 @@ def test_vectorised_brent_takes_the_coroutines_steps():
         assert i1 == i2
 
 
+def test_jump_rule_ends_the_iteration_on_a_jump_and_nowhere_else(monkeypatch):
+    """alpha_search.jump_rule (round 4): on a sign change without a root - chi^2 jumping across nu - the iteration ends once the
+    bracket is narrower than 1e-7 decades while both ends miss nu by more than 1e-4 nu, instead of bisecting on to brentq's
+    2e-12 (40-60 values).  Same answer from the coroutine and from the arrays; the root lies within 1e-7 of the jump; on
+    functions WITH a root (smooth, steep, several roots, poles outside) the iterates are those of plain brentq, value for
+    value; VINTERP_JUMP_STOP=0 restores brentq's own end."""
+    nu = 2600.
+    rule = AS.jump_rule(nu)
+    assert rule == (1e-7, 1e-4 * nu)
+    rng = np.random.default_rng(5)
+
+    def drive_all(f, jump):
+        g = AS.brentq_gen(-28., -27., fa=f(-28.), fb=f(-27.), jump=jump)
+        xs = []
+        try:
+            x = next(g)
+            while True:
+                xs.append(x)
+                x = g.send(f(x))
+        except StopIteration as stop:
+            return stop.value, xs
+    jumps, roots = [], []
+    for k in range(12):
+        r = rng.uniform(-27.9, -27.1)
+        jumps.append((r, lambda x, r=r, k=k: (-0.4 - 0.01 * k * (x + 28.)) if x < r else (3.1 + k)))          # |f| >> 0.26 on both sides
+        roots.append(lambda x, r=r, k=k: (5. + 40. * k) * nu * (x - r))                                # steep genuine roots
+        roots.append(lambda x, r=r, k=k: nu * ((x - r)**3 + 1e-4 * (x - r)))                           # flat genuine roots
+        roots.append(lambda x, r=r: math.tan((x - r) * 1.4) * nu)
+    for r, f in jumps:
+        (root, it, nf, oe), xs = drive_all(f, rule)
+        (root0, it0, nf0, oe0), xs0 = drive_all(f, None)
+        assert abs(root - r) <= 1e-7 and abs(oe - root) <= 1e-7 and (root - r) * (oe - r) <= 0.
+        assert abs(root0 - r) <= 4e-12 and xs == xs0[:len(xs)]                # the same iterates, fewer of them
+        assert nf <= nf0 - 10, (nf, nf0)
+    for f in roots:
+        assert drive_all(f, rule) == drive_all(f, None)
+    # the arrays take the coroutine's steps with the rule on
+    funcs = [f for _, f in jumps] + roots
+    bb = AS.BrentBatch(len(funcs))
+    for i, f in enumerate(funcs):
+        bb.add(i, -28., -27., f(-28.), f(-27.), jump=rule)
+    while bb.active.any():
+        idx, xs = bb.requests()
+        bb.feed(idx, np.array([funcs[i](x) for i, x in zip(idx.tolist(), xs.tolist())]))
+    for i, f in enumerate(funcs):
+        assert bb.results[i] == drive_all(f, rule)[0], i
+    monkeypatch.setenv('VINTERP_JUMP_STOP', '0')
+    assert AS.jump_rule(nu) is None
+
+
 def test_doubtful_walk_values_are_asked_for_together():
     """A record whose chi^2 sits within the sign margin of a target over a long stretch of the walk (the 50 decades where
     the systems are one and the same matrix, say) asks for their reference-grade values in one request, not decade by

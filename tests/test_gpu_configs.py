@@ -237,7 +237,9 @@ def test_single_record_brent_loop_in_c_equals_the_loop_in_python(monkeypatch):
         if ia:
             assert ia.get('iterations') == ib.get('iterations') and ia.get('other_end') == ib.get('other_end'), t
             its.append(ia.get('iterations', 0))
-    assert max(its) >= 30 and min(its) <= 16            # a jump record and ordinary ones were among them
+    # a jump record and ordinary ones were among them (the jump record: 39 iterations down to brentq's 2e-12 until round 3, 22
+    # with the early end on a jump of round 4 - alpha_search.jump_rule)
+    assert 18 <= max(its) <= 30 and min(its) <= 16
     eng.close()
 
 

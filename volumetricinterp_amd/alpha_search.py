@@ -17,6 +17,7 @@ called at interpolate.py:214 with the defaults xtol = 2e-12, rtol = 4 eps,
 maxiter = 100).
 """
 import math
+import os
 
 import numpy as np
 
@@ -33,11 +34,32 @@ def _signbit(x):
     return math.copysign(1.0, x) < 0
 
 
-def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
+JUMP_STOP_WIDTH = 1e-7      # decades of log10 alpha
+JUMP_STOP_FRAC = 1e-4       # of nu (= FitEngine.REDO_TOL: beyond it the guard does not accept a record as a root anyway)
+
+
+def jump_rule(nu):
+    """The early end of Brent's iteration on a JUMP of chi^2(alpha) - nu (round 4).  Where an eigenvalue
+    of X(alpha) crosses the truncation cut, chi^2 jumps: the function changes sign without a root, and brentq - in the
+    reference too - bisects that sign change down to its xtol = 2e-12 in 40-60 function values (15 % of the synthetic
+    default-order records; 44 ms against 16 ms for a record, and whichever workgroup draws one late ends the batch's launch
+    alone).  The guard's polish already stops on such a record once the sign change is confined to 1e-7 decades
+    (run_polish_batched): alpha means nothing beyond that - LAPACK drivers move the reference's own jumps by 1e-4 decades and
+    more.  So the iteration ends when the bracket is narrower than JUMP_STOP_WIDTH while BOTH ends miss nu by more than
+    JUMP_STOP_FRAC nu.  A genuine root never meets that: d chi^2 / d log10 alpha ~ nu per decade puts |f| ~ 1e-7 nu at that
+    width.  One rule, four places: brentq_gen, BrentBatch._top, brent_top in csrc/vi_brent.hip (device kernel and the C loop).
+    Returns (width, |f| threshold) or None (VINTERP_JUMP_STOP=0: brentq's own end, as in rounds 1-3)."""
+    if os.environ.get('VINTERP_JUMP_STOP', '1') == '0':
+        return None
+    return (JUMP_STOP_WIDTH, JUMP_STOP_FRAC * float(nu))
+
+
+def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER, jump=None):
     """Coroutine form of brentq: yields x, receives f(x); returns (root, iterations, funcalls, other_end) with other_end
     the far end of the final bracket (None when an end point is an exact zero).
 
-    fa / fb may be supplied when already known (the function is deterministic)."""
+    fa / fb may be supplied when already known (the function is deterministic).  jump: None (brentq as SciPy has it) or
+    (width, fmin) - see jump_rule."""
     xpre, xcur = xa, xb
     xblk, fblk, spre, scur = 0., 0., 0., 0.
     funcalls = 0
@@ -64,6 +86,8 @@ def brentq_gen(xa, xb, fa=None, fb=None, xtol=XTOL, rtol=RTOL, maxiter=MAXITER):
         delta = (xtol + rtol * abs(xcur)) / 2
         sbis = (xblk - xcur) / 2
         if fcur == 0 or abs(sbis) < delta:
+            return xcur, it, funcalls, xblk
+        if jump is not None and abs(xblk - xcur) <= jump[0] and abs(fcur) > jump[1]:      # |fblk| >= |fcur| here
             return xcur, it, funcalls, xblk
         if abs(spre) > delta and abs(fcur) < abs(fpre):
             if xpre == xblk:
@@ -103,9 +127,16 @@ class BrentBatch(object):
         self.funcalls = np.zeros(n, dtype=np.int64)
         self.active = np.zeros(n, dtype=bool)
         self.results = {}
+        self.jump_width = 0.                        # jump_rule: 0 = off
+        self.jump_fmin = np.full(n, np.inf)
 
-    def add(self, i, xa, xb, fa, fb):
-        """brentq_gen(xa, xb, fa=fa, fb=fb) up to its first yield."""
+    def add(self, i, xa, xb, fa, fb, jump=None):
+        """brentq_gen(xa, xb, fa=fa, fb=fb, jump=jump) up to its first yield."""
+        if jump is not None:
+            self.jump_width = float(jump[0])
+            self.jump_fmin[i] = float(jump[1])
+        else:
+            self.jump_fmin[i] = np.inf
         if fa == 0:
             self.results[i] = (xa, 0, 0, None)
             return
@@ -151,6 +182,8 @@ class BrentBatch(object):
         delta = (self.xtol + self.rtol * np.abs(xcur)) / 2
         sbis = (xblk - xcur) / 2
         term = (fcur == 0) | (np.abs(sbis) < delta)
+        if self.jump_width > 0.:
+            term = term | ((np.abs(xblk - xcur) <= self.jump_width) & (np.abs(fcur) > self.jump_fmin[idx]))
         with np.errstate(all='ignore'):
             c3 = (np.abs(spre) > delta) & (np.abs(fcur) < np.abs(fpre))
             stry_sec = -fcur * (xcur - xpre) / (fcur - fpre)
@@ -396,7 +429,7 @@ def chi2_search_gen(npts, multisection=0, refine=False, prefetch=1, defer_brent=
         # the driver runs Brent's iteration for all records at once (BrentBatch)
         return 'bracket', None, dict(sf=sf_used, alpha=alpha, alpha0=alpha0, val=val, val0=val0, nu=nu)
     else:
-        br = brentq_gen(alpha, alpha0, fa=val, fb=val0)
+        br = brentq_gen(alpha, alpha0, fa=val, fb=val0, jump=jump_rule(nu))
         try:
             x = next(br)
             while True:
@@ -459,7 +492,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
                 if brent_solver is not None and b['val'] != 0 and b['val0'] != 0:
                     deferred[i] = b                 # iterated with all the others once the walks are over
                     return
-                brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
+                brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'], jump=jump_rule(b['nu']))
                 if i in brent.results:
                     finish_brent(i)
             else:
@@ -501,7 +534,7 @@ def run_batched(npts_list, chi2_batch, prefetch=8, multisection=0, refine=False,
             for i, r_ in zip(ids, brent_solver(ids, [deferred[i] for i in ids])):
                 b = deferred.pop(i)
                 if r_ is None:
-                    brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
+                    brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'], jump=jump_rule(b['nu']))
                 else:
                     brent.results[i] = r_
                     nevals += int(r_[2])
@@ -746,7 +779,7 @@ def run_table_batched(npts_list, chi2_batch, prefetch=8, refine=False, brent_sol
         if brent_solver is not None and b['val'] != 0 and b['val0'] != 0:
             deferred[i] = b
             continue
-        brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
+        brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'], jump=jump_rule(b['nu']))
         if i in brent.results:
             finish_brent(i)
     if deferred:
@@ -754,7 +787,7 @@ def run_table_batched(npts_list, chi2_batch, prefetch=8, refine=False, brent_sol
         for i, r_ in zip(ids, brent_solver(ids, [deferred[i] for i in ids])):
             b = deferred.pop(i)
             if r_ is None:
-                brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'])
+                brent.add(i, b['alpha'], b['alpha0'], b['val'], b['val0'], jump=jump_rule(b['nu']))
             else:
                 brent.results[i] = r_
                 nevals += int(r_[2])
@@ -785,7 +818,7 @@ POLISH_BRENT_ROUNDS = 6
 
 
 def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, brent_rounds=POLISH_BRENT_ROUNDS,
-                       ksection=15):
+                       ksection=15, skip_brent=()):
     """Root polishing of the consistency guard (FitEngine._search_and_finalize): small brackets around an approximate
     root, an expensive f (cold solves), few records.  brackets = {rec: (xa, xb, fa, fb)}, f_batch(rec, x) -> f,
     ftol = {rec: |f| below which the record is done}, target = {rec: x} the point whose nearest sign change is wanted.
@@ -795,13 +828,17 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
     |f| <= ftol - a root for the guard's purposes - or its sign change is confined to xtol decades without |f| ever
     getting there: a jump of f (an eigenvalue of X(alpha) crossing the truncation threshold), where bisecting on to
     brentq's 2e-12 would cost 20 more rounds of one cold solve each for nothing.  Rounds are what costs (every one is a
-    launch that lasts as long as one cold solve): Brent's steps for all records first (superlinear on the smooth ones),
-    then, for the few left, K-section with `ksection` points per record and round (a fixed number: what a record gets must
-    not depend on how many others are being polished alongside).
+    launch that lasts as long as one cold solve): Brent's steps first (superlinear on smooth functions), at most
+    `brent_rounds` of them, then K-section with `ksection` points per record and round (a fixed number: what a record gets
+    must not depend on how many others are being polished alongside).  skip_brent: records that go to the K-section at once -
+    the guard lists those whose bracket shows the signature of a jump (both ends far from zero on a short bracket), where
+    Brent can only bisect: 16-fold per round instead of 2-fold (round 4: the jump record of the bench spent 8 rounds here).
+    A record's sequence of abscissae depends on its own bracket only; records in the two phases share the rounds' launches.
     Returns {rec: (root, rounds, other_end, how)}, how in {'ftol', 'jump', 'xtol'}."""
     out = {}
     state = {}                              # rec -> [lo, hi, flo, fhi, best_x, best_f]
     gens, pending = {}, {}
+    ksec = []
     rounds = 0
 
     def note(i, x, f):
@@ -832,18 +869,32 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
         state[i] = [lo, hi, flo, fhi, lo if abs(flo) <= abs(fhi) else hi, min(abs(flo), abs(fhi))]
         if finished(i):
             continue
+        if i in skip_brent:
+            ksec.append(i)
+            continue
         g = brentq_gen(xa, xb, fa=fa, fb=fb)
         try:
             pending[i] = next(g)
             gens[i] = g
         except StopIteration as stop:
             out[i] = (stop.value[0], 0, stop.value[3], 'xtol')
-    while gens and rounds < brent_rounds:
-        rec = np.array(sorted(gens), dtype=np.int32)
-        xs = np.array([pending[int(i)] for i in rec], dtype=np.float64)
-        vals = f_batch(rec, xs)
+    K = int(ksection)
+    while gens or ksec:
+        if gens and rounds >= brent_rounds:             # Brent's share is over: the records still iterating go to the K-section
+            ksec = sorted(set(ksec) | set(gens))
+            gens.clear()
+            pending.clear()
+        brec = sorted(gens)
+        rec = list(brec)
+        xs = [pending[i] for i in brec]
+        for i in ksec:
+            lo, hi = state[i][0], state[i][1]
+            for k in range(K):
+                rec.append(i)
+                xs.append(lo + (hi - lo) * (k + 1) / (K + 1))
+        vals = f_batch(np.asarray(rec, dtype=np.int32), np.asarray(xs, dtype=np.float64))
         rounds += 1
-        for i, x, v in zip(rec.tolist(), xs.tolist(), vals):
+        for i, x, v in zip(brec, xs[:len(brec)], vals[:len(brec)]):
             note(i, x, float(v))
             if finished(i):
                 del gens[i], pending[i]
@@ -853,20 +904,10 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
             except StopIteration as stop:
                 out[i] = (stop.value[0], rounds, stop.value[3], 'xtol')
                 del gens[i], pending[i]
-    left = sorted(gens)
-    while left:
-        K = int(ksection)
-        rec, xs = [], []
-        for i in left:
-            lo, hi = state[i][0], state[i][1]
-            for k in range(K):
-                rec.append(i)
-                xs.append(lo + (hi - lo) * (k + 1) / (K + 1))
-        vals = f_batch(np.asarray(rec, dtype=np.int32), np.asarray(xs, dtype=np.float64))
-        rounds += 1
-        for n, i in enumerate(left):
+        o = len(brec)
+        for n, i in enumerate(ksec):
             st = state[i]
-            pts = [(st[0], st[2])] + [(xs[n * K + k], float(vals[n * K + k])) for k in range(K)] + [(st[1], st[3])]
+            pts = ([(st[0], st[2])] + [(xs[o + n * K + k], float(vals[o + n * K + k])) for k in range(K)] + [(st[1], st[3])])
             pts = [p for p in pts if not math.isnan(p[1])]
             for x, f in pts:
                 if abs(f) < abs(st[5]):
@@ -882,5 +923,5 @@ def run_polish_batched(brackets, f_batch, ftol, target=None, xtol=POLISH_XTOL, b
                 st[0], st[1], st[2], st[3] = best[1:]
             else:                               # cannot happen with finite end values of opposite sign; do not loop
                 st[1] = st[0]
-        left = [i for i in left if not finished(i)]
+        ksec = [i for i in ksec if not finished(i)]
     return out

@@ -63,7 +63,24 @@ struct RebaseRule {
     int again_after;                  // one more move after this many requests ...
     double again_within;              // ... when two consecutive abscissae lie closer than this (records bisecting a jump)
     int again_on;
+    // the early end on a jump of chi^2 (alpha_search.jump_rule): the iteration ends once the sign change is confined to
+    // jump_width decades while both ends miss nu by more than jump_frac nu; 0 = brentq's own end
+    double jump_width, jump_frac;
 };
+
+// h_rebase of the C-ABI: 10 doubles
+__host__ inline int rule_from_host(const double* h, RebaseRule& rr)
+{
+    rr.nsched = (int)h[0];
+    if (rr.nsched < 0 || rr.nsched > 4) return -1;
+    for (int i = 0; i < 4; ++i) rr.sched[i] = h[1 + i];
+    rr.again_after = (int)h[5];
+    rr.again_within = h[6];
+    rr.again_on = (int)h[7];
+    rr.jump_width = h[8];
+    rr.jump_frac = h[9];
+    return 0;
+}
 
 __host__ __device__ __forceinline__ void rebase_decide(BrentState& s, const RebaseRule& rr)
 {
@@ -84,7 +101,7 @@ __host__ __device__ __forceinline__ void rebase_decide(BrentState& s, const Reba
 
 // brentq_gen from the top of its loop to the next request (alpha_search.py: BrentBatch._top for one record); returns true
 // when the iteration has ended (root in xcur, other end in xblk).
-__host__ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rtol)
+__host__ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, double rtol, double jump_width, double jump_fmin)
 {
 #pragma clang fp contract(off)
     if (s.fpre != 0.0 && s.fcur != 0.0 && (signbit(s.fpre) != signbit(s.fcur))) {
@@ -101,6 +118,7 @@ __host__ __device__ __forceinline__ bool brent_top(BrentState& s, double xtol, d
     const double delta = (xtol + rtol * fabs(s.xcur)) / 2;
     const double sbis = (s.xblk - s.xcur) / 2;
     if (s.fcur == 0.0 || fabs(sbis) < delta) return true;
+    if (jump_width > 0.0 && fabs(s.xblk - s.xcur) <= jump_width && fabs(s.fcur) > jump_fmin) return true;   // |fblk| >= |fcur| here
     if (fabs(s.spre) > delta && fabs(s.fcur) < fabs(s.fpre)) {
         double stry;
         if (s.xpre == s.xblk) {
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
             s.it = 1; s.funcalls = 0; s.status = 0;
             s.last_x = __builtin_nan("");
             s.nreq = 0; s.rebased = 0; s.rebase_now = 0;
-            s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+            s.done = brent_top(s, xtol, rtol, rr.jump_width, rr.jump_frac * nu) ? 1 : 0;
             if (!s.done) rebase_decide(s, rr);
             *st = s;
         }
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
                         s.status = 3;
                         s.done = 1;
                     } else {
-                        s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+                        s.done = brent_top(s, xtol, rtol, rr.jump_width, rr.jump_frac * nu) ? 1 : 0;
                     }
                 }
                 *st = s;
@@ -476,13 +494,9 @@ extern "C" int vi_brent_host_one_f64(vi_ctx* c, int32_t N, int64_t P, double* d_
     VI_REQUIRE(N > 0 && P > 0 && rec >= 0 && slot >= 0, "bad size");
     VI_HIP(hipSetDevice(c->device));
     RebaseRule rr;
-    rr.nsched = (int)h_rebase[0];
-    if (rr.nsched < 0 || rr.nsched > 4) { vi_set_error("vi_brent_host_one_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
-    for (int i = 0; i < 4; ++i) rr.sched[i] = h_rebase[1 + i];
-    rr.again_after = (int)h_rebase[5];
-    rr.again_within = h_rebase[6];
-    rr.again_on = (int)h_rebase[7];
+    if (rule_from_host(h_rebase, rr)) { vi_set_error("vi_brent_host_one_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
     const double xtol = 2e-12, rtol = 4 * 2.220446049250313e-16;
+    const double jump_fmin = rr.jump_frac * nu;
     const int maxiter = 100, max_sweeps = vi_max_sweeps();
     BrentState s;
     s.xpre = xa; s.xcur = xb; s.fpre = fa; s.fcur = fb;
@@ -490,7 +504,7 @@ extern "C" int vi_brent_host_one_f64(vi_ctx* c, int32_t N, int64_t P, double* d_
     s.it = 1; s.funcalls = 0; s.status = 0;
     s.last_x = __builtin_nan("");
     s.nreq = 0; s.rebased = 0; s.rebase_now = 0;
-    s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+    s.done = brent_top(s, xtol, rtol, rr.jump_width, jump_fmin) ? 1 : 0;
     if (!s.done) rebase_decide(s, rr);
     double* d_alpha = d_scratch;
     double* d_chi = d_scratch + 1;
@@ -529,7 +543,7 @@ extern "C" int vi_brent_host_one_f64(vi_ctx* c, int32_t N, int64_t P, double* d_
             s.status = 3;
             break;
         }
-        s.done = brent_top(s, xtol, rtol) ? 1 : 0;
+        s.done = brent_top(s, xtol, rtol, rr.jump_width, jump_fmin) ? 1 : 0;
         if (!s.done) rebase_decide(s, rr);
     }
     h_out[0] = s.xcur;
@@ -548,7 +562,7 @@ extern "C" int vi_brent_host_one_f64(vi_ctx* c, int32_t N, int64_t P, double* d_
 // sweep cap (the caller runs that record's iteration on the host), 3 = maxiter exceeded.
 extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P, double* d_D1, double* d_D2, double* d_yt,
                                  double* d_V, const double* d_AWA, const double* d_R, const double* d_y,
-                                 const double* h_rebase /* 8 doubles: nsched, sched[4], again_after, again_within, again_on */,
+                                 const double* h_rebase /* 10 doubles: nsched, sched[4], again_after, again_within, again_on, jump_width, jump_frac */,
                                  const double* d_At, const double* d_W,
                                  const double* d_b, const int32_t* d_rec, const int32_t* d_slot, const double* d_xa,
                                  const double* d_xb, const double* d_fa, const double* d_fb, const double* d_nu, double rcond,
@@ -586,12 +600,7 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
     double* VnW = VwW + (size_t)nwg * N * N;
     double* cw = VnW + (size_t)nwg * N * N;
     RebaseRule rr;
-    rr.nsched = (int)h_rebase[0];
-    if (rr.nsched < 0 || rr.nsched > 4) { vi_set_error("vi_brent_warm_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
-    for (int i = 0; i < 4; ++i) rr.sched[i] = h_rebase[1 + i];
-    rr.again_after = (int)h_rebase[5];
-    rr.again_within = h_rebase[6];
-    rr.again_on = (int)h_rebase[7];
+    if (rule_from_host(h_rebase, rr)) { vi_set_error("vi_brent_warm_f64: at most four re-basing thresholds"); return VI_ERR_INVALID; }
     int* queue = (int*)(cw + (size_t)nwg * N + 1);
     VI_HIP(hipMemsetAsync(queue, 0, sizeof(int), c->stream));
 #define VI_B(ITV)                                                                                                             \

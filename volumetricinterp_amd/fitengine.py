@@ -336,6 +336,16 @@ class FitEngine(object):
         return (done == len(sched) and self._nreq.get(r, 0) >= self.REBASE_AGAIN_AFTER
                 and abs(x - last) < self.REBASE_AGAIN_WITHIN and os.environ.get('VINTERP_REBASE2', '1') != '0')
 
+    def _brent_rule(self):
+        """h_rebase of vi_brent_warm_f64 / vi_brent_host_one_f64 (10 doubles): the re-basing schedule of the rotated systems and
+        the early end on a jump of chi^2 (alpha_search.jump_rule: width in decades, |chi^2 - nu| threshold as a fraction of nu;
+        zeros = brentq's own end)."""
+        sched = list(self._rebase_schedule()) if os.environ.get('VINTERP_REBASE', '1') != '0' else []
+        jr = alpha_search.jump_rule(1.)
+        return np.array([len(sched)] + (sched + [0.] * 4)[:4] + [self.REBASE_AGAIN_AFTER, self.REBASE_AGAIN_WITHIN,
+                        1. if (sched and os.environ.get('VINTERP_REBASE2', '1') != '0') else 0.,
+                        jr[0] if jr else 0., jr[1] if jr else 0.], dtype=np.float64)
+
     def _rebase_schedule(self):
         """Thresholds (decades between two consecutive requests of a record) at which its rotated system is moved to the
         current request: the k-th move happens the first time two consecutive requests lie closer than schedule[k]."""
@@ -666,9 +676,7 @@ class FitEngine(object):
         dnu = up('nu', [b['nu'] for b in brackets], np.float64)
         droot, dother = self._buf('db_root', (n,)), self._buf('db_other', (n,))
         dit, dfc, dst = (self._buf('db_' + k, (n,), np.int32) for k in ('it', 'fc', 'st'))
-        sched = list(self._rebase_schedule()) if os.environ.get('VINTERP_REBASE', '1') != '0' else []
-        rule = np.array([len(sched)] + (sched + [0.] * 4)[:4] + [self.REBASE_AGAIN_AFTER, self.REBASE_AGAIN_WITHIN,
-                        1. if (sched and os.environ.get('VINTERP_REBASE2', '1') != '0') else 0.], dtype=np.float64)
+        rule = self._brent_rule()
         _lib.check(_lib.lib.vi_brent_warm_f64(h, n, N, self.P, dD1.ptr, dD2.ptr, dyt.ptr, dV.ptr, self.dAWA.ptr,
                                               self.R[name].ptr, self.dy.ptr, rule.ctypes.data_as(_lib.VOIDP), self.At.ptr,
                                               self.dW.ptr, self.db.ptr, drec.ptr, dslot.ptr, dxa.ptr, dxb.ptr, dfa.ptr, dfb.ptr, dnu.ptr,
@@ -704,9 +712,7 @@ class FitEngine(object):
         """_device_brent's contract for the records of a fit that is driven from the host (one record)."""
         N, h = self.N, self.ctx.handle
         out = []
-        sched = list(self._rebase_schedule()) if os.environ.get('VINTERP_REBASE', '1') != '0' else []
-        rule = np.array([len(sched)] + (sched + [0.] * 4)[:4] + [self.REBASE_AGAIN_AFTER, self.REBASE_AGAIN_WITHIN,
-                        1. if (sched and os.environ.get('VINTERP_REBASE2', '1') != '0') else 0.], dtype=np.float64)
+        rule = self._brent_rule()
         for r, b in zip([int(r) for r in recs], brackets):
             if r not in self._warm_slot:
                 # the rotated system at the middle of the record's unit bracket: decomposed alongside the walk, or now
@@ -1139,40 +1145,48 @@ class FitEngine(object):
                     bad.append(t)
             return bad
         bad = violators()
+        inf['polished_cold'] = []
         if bad and self.warm_enabled():
-            # Is the miss a jump of the cold function itself?  Brent ends on a bracket ~1e-12 wide (root, other_end); if
-            # the COLD chi^2 - nu changes sign across it, the cold function has a sign-changing jump there (an eigenvalue
-            # of X(alpha) crossing the truncation threshold or zero) and the root is as good an answer for it as for the
-            # warm one: no redo.  One extra cold solve per suspect record, in one batch.
-            sus = [t for t in bad if inf['info'][t].get('other_end') is not None]
-            if sus:
-                oe = np.array([inf['info'][t]['other_end'] for t in sus], dtype=np.float64)
-                c_oe = self.chi2_batch(np.asarray(sus, dtype=np.int32), {name: np.power(10., oe)})
-                for t, c in zip(sus, c_oe):
-                    nu = inf['info'][t]['sf'] * npts[t]
+            # ONE launch of cold solves for all suspect records (round 4; until then the far end, the scan and every polish
+            # round were launches of their own, each as long as a cold solve - 20 of the 42 ms of the bench's jump record):
+            #  * the far end of Brent's final bracket (root, other_end).  Is the miss a jump of the cold function itself?  If
+            #    the COLD chi^2 - nu changes sign across that bracket - 2e-12 wide, or up to 1e-7 where the iteration ended on
+            #    the jump rule - the cold function has a sign-changing jump there (an eigenvalue of X(alpha) crossing the
+            #    truncation threshold or zero) and the root is as good an answer for it as for the warm one: no redo;
+            #  * otherwise the warm search was misled (its chi^2 differs from the cold one by more than REDO_TOL there - next
+            #    to the poles and jumps of chi^2(alpha) the rotated system is not accurate enough; the cold function's jump
+            #    sits 1e-6 decades from the warm one's in the median).  The warm root is still close to a root or jump of the
+            #    cold function: a sign change of the COLD chi^2 - nu within 1e-6 .. 1e-1 decades of it (12 cold solves per
+            #    record) gives a small bracket for alpha_search.run_polish_batched.
+            deltas = np.array([-1e-1, -1e-2, -1e-3, -1e-4, -1e-5, -1e-6, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])
+            roots = np.array([inf['info'][t]['log10_alpha'] for t in bad])
+            has_oe = [inf['info'][t].get('other_end') is not None for t in bad]
+            rec_l, xs_l = [], []
+            for i, t in enumerate(bad):
+                if has_oe[i]:
+                    rec_l.append(t)
+                    xs_l.append(inf['info'][t]['other_end'])
+                rec_l += [t] * len(deltas)
+                xs_l += (roots[i] + deltas).tolist()
+            cv = self.chi2_batch(np.asarray(rec_l, dtype=np.int32), {name: np.power(10., np.asarray(xs_l, dtype=np.float64))})
+            brackets, skip_brent = {}, set()
+            o = 0
+            for i, t in enumerate(bad):
+                nu = inf['info'][t]['sf'] * npts[t]
+                if has_oe[i]:
+                    c = cv[o]
+                    o += 1
                     if (c - nu) * (chi[t] - nu) < 0:
                         inf['info'][t]['jump'] = True
                         inf['info'][t]['chi2_other_end_minus_nu'] = float(c - nu)
-                bad = [t for t in bad if not inf['info'][t].get('jump')]
-        inf['polished_cold'] = []
-        if bad and self.warm_enabled():
-            # Not a jump: the warm search was misled (its chi^2 differs from the cold one by more than REDO_TOL there -
-            # next to the poles of chi^2(alpha) that the indefinite curvature matrix produces, the rotated system is not
-            # accurate enough).  The warm root is still close to a root of the cold function: look for a sign change of the
-            # COLD chi^2 - nu within 1e-4 .. 1e-1 decades of it (one batch of 8 cold solves per record) and run Brent on
-            # that small bracket with cold solves (alpha_search.run_polish_batched: ~10 rounds instead of the 20-40 of a search
-            # over the unit bracket to brentq's xtol).
-            deltas = np.array([-1e-1, -1e-2, -1e-3, -1e-4, 1e-4, 1e-3, 1e-2, 1e-1])
-            rec = np.repeat(np.asarray(bad, dtype=np.int32), len(deltas))
-            roots = np.array([inf['info'][t]['log10_alpha'] for t in bad])
-            xs = (roots[:, None] + deltas[None, :]).ravel()
-            cvals = self.chi2_batch(rec, {name: np.power(10., xs)}).reshape(len(bad), len(deltas))
-            brackets = {}
-            for i, t in enumerate(bad):
-                nu = inf['info'][t]['sf'] * npts[t]
+                cvals = cv[o:o + len(deltas)]
+                o += len(deltas)
+                if inf['info'][t].get('jump'):
+                    continue
                 lo, hi = inf['info'][t]['bracket']
-                pts = sorted([(roots[i] + d, c - nu) for d, c in zip(deltas, cvals[i]) if lo <= roots[i] + d <= hi]
-                             + [(roots[i], chi[t] - nu)])
+                lo, hi = min(lo, hi), max(lo, hi)
+                pts = sorted([(float(roots[i] + d), float(c - nu)) for d, c in zip(deltas, cvals) if lo <= roots[i] + d <= hi]
+                             + [(float(roots[i]), float(chi[t] - nu))])
                 best = None
                 for (xa, fa), (xb, fb) in zip(pts[:-1], pts[1:]):
                     if np.isfinite(fa) and np.isfinite(fb) and fa * fb < 0:
@@ -1181,6 +1195,11 @@ class FitEngine(object):
                             best = (dist, xa, xb, fa, fb)
                 if best is not None:
                     brackets[t] = best[1:]
+                    # the signature of a jump (or pole): a sign change on a short bracket whose ends both miss nu by more
+                    # than REDO_TOL nu - a root there would need a slope of 2 nu per 1e-4 decades.  Brent could only bisect it.
+                    if (abs(best[2] - best[1]) <= 1e-4 * (1. + 1e-9) and min(abs(best[3]), abs(best[4])) > self.REDO_TOL * nu):
+                        skip_brent.add(t)
+            bad = [t for t in bad if not inf['info'][t].get('jump')]
             if brackets:
                 nus = {t: inf['info'][t]['sf'] * npts[t] for t in brackets}
 
@@ -1188,14 +1207,15 @@ class FitEngine(object):
                     return self.chi2_batch(r, {name: np.power(10., x)}) - np.array([nus[int(t)] for t in r])
                 # stop at |chi^2 - nu| <= CONSISTENCY_TOL nu, or when the sign change is confined to 1e-7 decades (a jump):
                 # every round is a launch as long as one cold solve, and alpha means nothing beyond ~1e-6 decades here
+                root_of = {t: float(inf['info'][t]['log10_alpha']) for t in brackets}
                 sol = alpha_search.run_polish_batched(brackets, f_batch, {t: self.CONSISTENCY_TOL * nus[t] for t in brackets},
-                                                      target={t: float(roots[bad.index(t)]) for t in brackets})
+                                                      target=root_of, skip_brent=skip_brent)
                 done = sorted(sol)
                 for t in done:
                     root, iters, oe, how = sol[t]
                     params[t][name] = float(np.power(10., root))
                     inf['info'][t].update(log10_alpha=root, other_end=oe, polished_cold=True, polish_iterations=iters,
-                                          polish_end=how, warm_log10_alpha=float(roots[bad.index(t)]))
+                                          polish_end=how, warm_log10_alpha=root_of[t])
                 C2, V2, c2, r2, g2 = self.finalize(params, calccov=calccov, only=set(done), compact=True)
                 at = {t: i for i, t in enumerate(g2)}
                 for t in done:
