@@ -121,6 +121,46 @@ def test_L7_fit_records_screened(tmp_path, monkeypatch, name, root):
         assert it.fit_stats['solves'] < int(f['evalC_calls'])
 
 
+SCREENED_R4 = ['k4l2', 'k6l2', 'k12l2', 'k6l2_c2', 'k12l2_c2', 'k8l2_c5']
+
+
+@pytest.mark.parametrize('tag', SCREENED_R4)
+def test_L7_screened_orders_and_geometries(tmp_path, tag):
+    """VERDICT round 3 item 6 - wider ground for the 1e-6 gate.  tools/gen_golden.py (gen_screened) ran the screening rule of
+    SURVEY 8c over thirteen more orders / geometries with the reference itself (three runs each: as is, and twice with 1e-14
+    relative noise on its basis; tests/golden/screening.npz keeps the outcome of all thirteen).  The six that reproduce
+    themselves to better than 1e-7 - MAXL 2 with MAXK 4, 6, 12 at 11 x 50, MAXK 6 and 12 at 26 x 100, MAXK 8 at 64 x 200
+    (12 800 points per record), curvature regularisation by the reference's own Omega of that order - are gated here at the
+    north-star tolerance: coefficients and densities (8^3 grid) 1e-6, covariance 1e-5, chi^2 1e-6, log10 alpha 1e-6, and the
+    records the reference ends without a root (NaN rows, interpolate.py:558-563) are NaN rows here.  What failed the screen
+    and is therefore NOT gated at 1e-6: MAXK 16 x MAXL 2 (7e-7), every 0thorder case at MAXL 3 (1e-3 .. 1e-2),
+    MAXK 12 x MAXL 2 0thorder (5e-7), the 64 x 200 0thorder case (1.2e-6), RBF with 27 centres at 26 x 100 (2e-6)."""
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.estimate import Estimate
+    f = load_golden('fit_scr_' + tag)
+    regm, reg = reg_of(f)
+    has = np.all(np.isfinite(f['Coeffs']), axis=1)
+    assert has.any() and np.nanmax(f['self_noise']) < 1e-7
+    it = make_interp(tmp_path, str(f['cfg']))
+    res = it.fit_records(f['lat'], f['lon'], f['alt'], f['value'], f['error'], regm)
+    g = synth.query_grid(8)
+    es = Estimate.from_arrays(f['Coeffs'], f['Covariance'], f['utime'], f['hull_vert'], str(f['cfg']))
+    worst = 0.
+    for t in range(f['value'].shape[0]):
+        if not has[t]:
+            assert np.all(np.isnan(res['Coeffs'][t])) and np.isnan(res['chi_sq'][t]), t
+            continue
+        worst = max(worst, rel(res['Coeffs'][t], f['Coeffs'][t]))
+        assert rel(res['Coeffs'][t], f['Coeffs'][t]) <= 1e-6, t
+        assert rel(res['Covariance'][t], f['Covariance'][t]) <= 1e-5, t
+        assert abs(res['chi_sq'][t] - f['chi_sq'][t]) <= 1e-6 * f['chi_sq'][t]
+        assert abs(math.log10(res['reg_params'][t][reg]) - math.log10(f['alpha'][t])) <= 1e-6
+        d_ref = es.evaluate_coeffs(f['Coeffs'][t:t + 1], *g, check_hull=False)[0]
+        d_gpu = es.evaluate_coeffs(res['Coeffs'][t:t + 1], *g, check_hull=False)[0]
+        assert rel(d_gpu, d_ref) <= 1e-6, t
+    print('fit_scr_%s: worst rel(C) vs the reference %.2e (reference self-noise %.1e)' % (tag, worst, np.nanmax(f['self_noise'])))
+
+
 @pytest.mark.parametrize('regmat_mode', ['default', 'gauss'])
 def test_L7_fit_with_the_build_s_own_psi(tmp_path, monkeypatch, regmat_mode):
     """VERDICT round 3, missing #5: every 0thorder parity test fed the fixture's R.  Here the regularisation matrix is the one

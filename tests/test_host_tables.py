@@ -98,3 +98,21 @@ def test_default_psi_is_the_reference_s_and_finite_limits_converge(monkeypatch):
         mf = Model(io.StringIO(cfg % (4, 3, zmax)))
         Pq, Pg = regmat.eval_psi(mf), regmat.eval_psi_gauss(mf)
         assert np.max(np.abs(Pg - Pq)) <= 5e-10 * np.max(np.abs(Pq)), zmax
+
+
+def test_regmat_worker_processes_give_the_same_bits(monkeypatch):
+    """The angular integrals of Omega / Psi spread over worker processes (regmat._tp_parallel: from 3000 distinct (l, m) pairs
+    on, i.e. at the doubled order of BASELINE configs[4], where one process needs 65 s for Omega): the same QUADPACK calls on
+    the same scalars - the matrices are the reference's BIT FOR BIT whichever process computed an entry."""
+    import io
+    from conftest import load_golden
+    from volumetricinterp_amd import regmat
+    from volumetricinterp_amd.models.sphharmlag import Model
+    ref = load_golden('regmat')
+    m = Model(io.StringIO('[DEFAULT]\n[MODEL]\nNAME = sphharmlag\nMAXK = 4\nMAXL = 3\nCAP_LIM = 10\nMAX_Z_INT = INF\nLATCP = 78\n'
+                          'LONCP = 262\n'))
+    monkeypatch.setenv('VINTERP_REGMAT_WORKERS', '2')
+    assert np.array_equal(regmat.eval_omega(m), ref['k4l3_curvature'])
+    assert np.array_equal(regmat.eval_psi(m), ref['k4l3_0thorder'])
+    monkeypatch.delenv('VINTERP_REGMAT_WORKERS')
+    assert regmat._workers(1296) == 1 and regmat._workers(20736) >= 1

@@ -597,6 +597,73 @@ def gen_eval(workdir):
     save('eval', **out)
 
 
+SCREEN_CANDIDATES = [
+    # tag, model kwargs, geometry (beams, ranges), records, regularisation
+    ('k4l2', dict(maxk=4, maxl=2, cap=10), synth.GEOM_C1, 3, 'curvature'),
+    ('k6l2', dict(maxk=6, maxl=2, cap=10), synth.GEOM_C1, 3, 'curvature'),
+    ('k12l2', dict(maxk=12, maxl=2, cap=10), synth.GEOM_C1, 3, 'curvature'),
+    ('k16l2', dict(maxk=16, maxl=2, cap=10), synth.GEOM_C1, 3, 'curvature'),
+    ('k6l2_c2', dict(maxk=6, maxl=2, cap=10), synth.GEOM_C2, 2, 'curvature'),
+    ('k12l2_c2', dict(maxk=12, maxl=2, cap=10), synth.GEOM_C2, 2, 'curvature'),
+    ('k8l2_c5', dict(maxk=8, maxl=2, cap=10), synth.GEOM_C5, 2, 'curvature'),
+    ('k4l3_psi', dict(maxk=4, maxl=3, cap=10), synth.GEOM_C1, 3, '0thorder'),
+    ('k6l3_psi', dict(maxk=6, maxl=3, cap=10), synth.GEOM_C1, 3, '0thorder'),
+    ('k8l3_psi_c2', dict(maxk=8, maxl=3, cap=10), synth.GEOM_C2, 2, '0thorder'),
+    ('k12l2_psi', dict(maxk=12, maxl=2, cap=10), synth.GEOM_C1, 3, '0thorder'),
+    ('k8l2_psi_c5', dict(maxk=8, maxl=2, cap=10), synth.GEOM_C5, 2, '0thorder'),
+    ('rbf3_c2', dict(name='radbasfun', ngrid=3), synth.GEOM_C2, 2, ''),
+]
+
+
+def gen_screened(workdir):
+    """widen the ground the 1e-6 gate stands on.  The screening rule of SURVEY 8c over more orders and
+    geometries: the reference fits each candidate twice - as is, and with 1e-14 relative noise on its basis; a candidate
+    whose coefficients reproduce themselves (self-noise rel(dC) below SCREEN on every record that has a root) becomes a
+    fixture tests/golden/fit_scr_<tag>.npz, gated at 1e-6 by tests/test_gpu_fit.py.  The regularisation matrix is the
+    reference's own (its eval_omega / eval_psi at that order).  A summary of all candidates, passed or not, goes to
+    tests/golden/screening.npz (and to stdout)."""
+    SCREEN = float(os.environ.get('VI_SCREEN', '1e-7'))
+    only = os.environ.get('VI_SCREEN_ONLY')
+    summary = {}
+    for tag, kw, geom, T, reg in SCREEN_CANDIDATES:
+        if only and tag not in only.split(','):
+            continue
+        name = kw.get('name', 'sphharmlag')
+        cfg = config_text(reglist=reg, **kw)
+        m = ref_model(cfg, name)
+        regm = {}
+        if reg:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                regm = {reg: m.eval_reg_matricies[reg]()}
+        lat, lon, alt = synth.beams(*geom, seed=0)
+        A = m.basis(lat, lon, alt)
+        value, error = synth.synth_records(A, T, seed0=4000)
+        utime = synth.unix_times(T)
+        import time
+        t0 = time.time()
+        it, rec = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, regm)
+        it2, _ = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, regm, perturb=91)
+        it3, _ = run_ref_fit(cfg, workdir, lat, lon, alt, utime, value, error, regm, perturb=92)
+        has = np.all(np.isfinite(it.Coeffs), axis=1)
+        same_nan = bool(np.array_equal(has, np.all(np.isfinite(it2.Coeffs), axis=1))
+                        and np.array_equal(has, np.all(np.isfinite(it3.Coeffs), axis=1)))
+        noise = np.array([max(rel(it2.Coeffs[t], it.Coeffs[t]), rel(it3.Coeffs[t], it.Coeffs[t])) if has[t] else np.nan
+                          for t in range(T)])
+        alphas = np.array([rp[reg] for rp in rec.reg_params[:T]], dtype=np.float64) if reg else np.zeros(T)
+        ok = bool(same_nan and has.any() and np.nanmax(noise) < SCREEN)
+        summary[tag] = np.array([m.nbasis, lat.size, float(has.sum()), float(np.nanmax(noise)) if has.any() else np.nan, float(ok)])
+        print('%-12s N=%3d P=%5d roots %d/%d  self-noise %s  alpha %s  %s  (%.0f s)'
+              % (tag, m.nbasis, lat.size, has.sum(), T, noise, alphas, 'PASS' if ok else 'fail', time.time() - t0), flush=True)
+        if ok:
+            save('fit_scr_' + tag, cfg=np.array(cfg), reg=np.array(reg), R=regm[reg] if reg else np.zeros((0, 0)),
+                 lat=lat, lon=lon, alt=alt, utime=utime, value=value, error=error, Coeffs=it.Coeffs,
+                 Covariance=it.Covariance, chi_sq=it.chi_sq, hull_vert=it.hull_vert, alpha=alphas, self_noise=noise,
+                 evalC_calls=np.array(rec.evalC_calls))
+    if not only:
+        save('screening', **summary)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -607,7 +674,7 @@ def main():
     workdir = tempfile.mkdtemp(prefix='vi_gold_')
     steps = [('basis', gen_basis), ('regmat', gen_regmat), ('fit', gen_fit), ('gcv', gen_gcv), ('grad', gen_grad), ('eval', gen_eval),
              ('default_many', gen_default_many), ('default_roots', gen_default_roots),
-             ('default_drivers', gen_default_drivers)]
+             ('default_drivers', gen_default_drivers), ('screened', gen_screened)]
     for name, fn in steps:
         if args.only and args.only != name:
             continue
