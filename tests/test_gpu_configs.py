@@ -567,6 +567,48 @@ def test_c4_doubled_order_fit_end_to_end():
     eng.close()
 
 
+def test_c4_doubled_order_batch_of_64():
+    """configs[4] as a BATCH: 64 records of the 64 x 200 geometry at MAXK 8 / MAXL 12 (N = 1152) fitted
+    in one call - the rocSOLVER path, where the cost per solve falls with the launch size (2.7 ms per system from 64 systems
+    on, 10.6 ms for four) and the walk of the whole batch is issued in launches of at most 4 GiB of systems (404).  Records are
+    independent (interpolate.py:511-579): every record that ends on a root meets its chi^2 target to 1e-6 nu, and one record
+    re-fitted ALONE gives the same alpha (1e-7 decades) and coefficients (1e-6) - the library picks its kernels by batch size
+    at this order, so bit equality is not on offer, the north-star tolerance is."""
+    import time
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    m, ctx, eng0, A, _ = _engine(CFG1152, synth.GEOM_C5, R=np.eye(1152))
+    eng0.close()
+    P, N = A.shape
+    T = 64
+    value, error = synth.synth_records(A, T, seed0=1000)
+    W = error**-2.
+    R = np.eye(N) * np.mean(np.abs(np.einsum('pn,p,pn->n', A, W[0], A)))
+    eng = FitEngine(ctx, ctx.to_device(np.ascontiguousarray(A.T)), P, N, {'curvature': R}, ['curvature'])
+    assert not eng.warm_enabled() and eng._max_batch() == 404          # 4 GiB of systems per launch
+    t0 = time.perf_counter()
+    res = eng.fit(W, value, [P] * T)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    oc = res['search']['curvature']['outcomes']
+    roots = [t for t in range(T) if oc[t] == 'root']
+    assert len(roots) >= T // 2, oc
+    for t in roots:
+        nu = res['search']['curvature']['info'][t]['sf'] * P
+        assert abs(res['chi_sq'][t] - nu) <= 1e-6 * nu, (t, res['chi_sq'][t], nu)
+    assert np.all(np.isfinite(res['Coeffs'][roots])) and np.all(np.isfinite(res['Covariance'][roots][:, 0, 0]))
+    t1 = roots[len(roots) // 2]
+    one = eng.fit(W[t1:t1 + 1], value[t1:t1 + 1], [P])
+    a1, aT = one['reg_params'][0]['curvature'], res['reg_params'][t1]['curvature']
+    assert abs(math.log10(a1) - math.log10(aT)) <= 1e-7, (a1, aT)
+    assert rel(one['Coeffs'][0], res['Coeffs'][t1]) <= 1e-6
+    assert rel(A @ one['Coeffs'][0], A @ res['Coeffs'][t1]) <= 1e-6
+    print('configs[4] batch: %d records in %.1f s = %.0f ms per record (%d solves, %d launches), %d roots'
+          % (T, dt, dt / T * 1e3, eng.stats['solves'], eng.stats['launches'], len(roots)))
+    assert dt <= 90., dt
+    eng.close()
+
+
 # ---- configs[4]: fp32 vs fp64 tolerance sweep of the evaluation ---------------------------------------------------------
 @pytest.mark.parametrize('maxk,maxl,cap', [(4, 6, 10), (8, 2, 10), (8, 12, 15)])
 def test_c4_fp32_chain_sweep(capsys, maxk, maxl, cap):

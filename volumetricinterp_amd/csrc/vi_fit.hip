@@ -727,6 +727,23 @@ extern "C" int vi_solve_trunc_f64(vi_ctx* c, int64_t B, int32_t N, double* d_X, 
         }
         return VI_OK;
     }
+    // The library path in launches of at most 4 GiB of systems (404 at N = 1152): one batched syevd call on 1618 systems of
+    // that order - 17 GB, 2.147e9 elements, a hair under 2^31 - ended in a GPU memory access fault inside the library
+    // (round 4); up to 392 systems per call is what every earlier round ran.  The cost per system is flat from 64 systems on.
+    {
+        int64_t Bmax = (int64_t)(((size_t)4 << 30) / ((size_t)N * N * sizeof(double)));
+        if (Bmax < 1) Bmax = 1;
+        if (B > Bmax) {
+            for (int64_t i0 = 0; i0 < B; i0 += Bmax) {
+                const int64_t bc = (B - i0) < Bmax ? (B - i0) : Bmax;
+                const int rc2 = vi_solve_trunc_f64(c, bc, N, d_X + i0 * N * N, d_rec ? d_y : d_y + i0 * N, d_rec ? d_rec + i0 : nullptr,
+                                                   rcond, d_C + i0 * N, d_rank ? d_rank + i0 : nullptr, pinv_rcond,
+                                                   d_H ? d_H + i0 * N * N : nullptr);
+                if (rc2 != VI_OK) return rc2;
+            }
+            return VI_OK;
+        }
+    }
     // workspace: eigenvalues [B][N], E [B][N], info [B], (Vs [B][N][N] when H is wanted)
     const size_t nD = (size_t)B * N;
     size_t bytes = 2 * nD * sizeof(double) + (size_t)B * sizeof(double) + (size_t)B * sizeof(int) * 4 + 256;

@@ -254,12 +254,21 @@ class FitEngine(object):
         self.stats['launches'] += 1
         return drec, dC, dH, drank
 
+    def _max_batch(self):
+        """Systems per solver launch: MAX_BATCH, or fewer where the systems themselves would exceed 4 GiB (N = 1152, the
+        doubled order of BASELINE configs[4]: 10.6 MB per system -> 404 per launch; rocSOLVER's batched syevd costs the same per
+        system from 64 systems on).  Measured, round 4: ONE launch of 1618 systems at that order (17 GB, 2.147e9 elements - a
+        hair under 2^31) ended in a GPU memory access fault inside the library call; launches of up to 392 systems (4.2 GB) are
+        what rounds 1-3 ran and tested."""
+        return int(max(1, min(MAX_BATCH, (4 << 30) // (8 * self.N * self.N))))
+
     def chi2_batch(self, rec, alphas):
         """chi^2 of the regularised solution for B (record, {name: alpha}) pairs -> host array (B,)."""
         rec = np.ascontiguousarray(rec, dtype=np.int32)
         out = np.empty(len(rec))
-        for s in range(0, len(rec), MAX_BATCH):
-            e = min(len(rec), s + MAX_BATCH)
+        mb = self._max_batch()
+        for s in range(0, len(rec), mb):
+            e = min(len(rec), s + mb)
             B = e - s
             drec, dC, _, _ = self._solve_chunk(rec[s:e], {k: v[s:e] for k, v in alphas.items()}, False, 's_')
             dchi = self._buf('s_chi2', (B,))
@@ -545,9 +554,10 @@ class FitEngine(object):
         drec = self._buf('w_rec', (B,), np.int32).upload(rec_o)
         dal = self._buf('w_alpha', (B,)).upload(alpha_o)
         if nc:
-            dX = self._buf('w_X', (min(nc, MAX_BATCH), N, N))
-            for s0 in range(0, nc, MAX_BATCH):
-                bc = min(MAX_BATCH, nc - s0)
+            mb = self._max_batch()
+            dX = self._buf('w_X', (min(nc, mb), N, N))
+            for s0 in range(0, nc, mb):
+                bc = min(mb, nc - s0)
                 _lib.check(_lib.lib.vi_form_system_f64(h, bc, N, self.dAWA.ptr, drec.offset_ptr(s0), dal.offset_ptr(s0),
                                                        self.R[name].ptr, dX.ptr), 'vi_form_system_f64')
                 _lib.check(_lib.lib.vi_solve_trunc_f64(h, bc, N, dX.ptr, self.dy.ptr, drec.offset_ptr(s0), EPS,
