@@ -168,13 +168,18 @@ class Estimate(object):
         if Q:
             h = self.model.handle()
             ctx = self.model._ctx
-            d = [ctx.to_device(a) for a in (lat, lon, alt)]
-            dC_ = ctx.to_device(np.ascontiguousarray(C, dtype=np.float64))
-            dout = ctx.empty((Q, 3))
-            _lib.check(_lib.lib.vi_eval_grad_f64(h, Q, d[0].ptr, d[1].ptr, d[2].ptr, dC_.ptr, dout.ptr), 'vi_eval_grad_f64')
-            out = dout.download()
-            for a in d + [dC_, dout]:
-                a.free()
+            bufs = []                               # freed whatever happens (a failed call must not keep device memory)
+            try:
+                for a in (lat, lon, alt):
+                    bufs.append(ctx.to_device(a))
+                bufs.append(ctx.to_device(np.ascontiguousarray(C, dtype=np.float64)))
+                bufs.append(ctx.empty((Q, 3)))
+                _lib.check(_lib.lib.vi_eval_grad_f64(h, Q, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr),
+                           'vi_eval_grad_f64')
+                out = bufs[4].download()
+            finally:
+                for a in bufs:
+                    a.free()
             if check_hull:
                 out[~self.check_hull(lat, lon, alt)] = np.nan
         return out.reshape(gdlat.shape + (3,))
@@ -195,13 +200,18 @@ class Estimate(object):
         if Q:
             h = self.model.handle()
             ctx = self.model._ctx
-            d = [ctx.to_device(a) for a in (lat, lon, alt)]
-            ddC = ctx.to_device(np.ascontiguousarray(dC, dtype=np.float64))
-            dout = ctx.empty((Q,))
-            _lib.check(_lib.lib.vi_eval_err_f64(h, Q, d[0].ptr, d[1].ptr, d[2].ptr, ddC.ptr, dout.ptr), 'vi_eval_err_f64')
-            out = dout.download()
-            for a in d + [ddC, dout]:
-                a.free()
+            bufs = []
+            try:
+                for a in (lat, lon, alt):
+                    bufs.append(ctx.to_device(a))
+                bufs.append(ctx.to_device(np.ascontiguousarray(dC, dtype=np.float64)))
+                bufs.append(ctx.empty((Q,)))
+                _lib.check(_lib.lib.vi_eval_err_f64(h, Q, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr),
+                           'vi_eval_err_f64')
+                out = bufs[4].download()
+            finally:
+                for a in bufs:
+                    a.free()
             if check_hull:
                 out[~self.check_hull(lat, lon, alt)] = np.nan
         return out.reshape(gdlat.shape)
