@@ -5,6 +5,8 @@ NumPy / LAPACK on the same inputs, at the benchmarked order (N = 144, 26 x 100 p
   vi_decompose_f64 / vi_warm_finish_f64   the two phases of vi_warm_prepare_f64;
   vi_warm_rebase_f64   the rotated system moved next to the root;
   vi_chi2_f64          the fixed-order chi^2 kernel, whatever the batch."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from conftest import load_golden, rel
 from test_gpu_configs import _engine, CFG144, EPS
 
 pytestmark = pytest.mark.gpu
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -329,3 +332,61 @@ def test_device_brent_with_more_than_16384_points_per_record(monkeypatch):
         assert a1 == a2 or (np.isnan(a1) and np.isnan(a2)), (t, a1, a2)
         assert np.array_equal(dev['Coeffs'][t], host['Coeffs'][t], equal_nan=True), t
     eng.close()
+
+
+def test_role_separated_k3_gives_the_bits_of_the_two_barrier_kernel(tmp_path):
+    """K3 exists twice (round 4): jacobi_system (two barriers per round, every order) and jacobi_system_v2 (vi_jacobi_v2_device.h:
+    a set-up wave that keeps the diagonal blocks in registers and takes the cross parts from a mailbox, update waves with one
+    block per thread; used from N = 93 on, in k_jacobi_solve and inside k_brent_warm).  Same ordering, same rotation formulas,
+    same arithmetic per element: the eigenvalues and sweep counts of 24 systems (well-conditioned and graded, rank-deficient,
+    indefinite) at N = 144 and N = 100, and a whole 12-record default-order fit (batch path: shared walk, device-side Brent,
+    final solves, guard) must agree BIT FOR BIT between `VINTERP_K3=v1` and the default.  The choice is read once per process,
+    hence two child processes."""
+    import subprocess
+    import sys
+    script = tmp_path / 'k3_bits.py'
+    script.write_text('''
+import ctypes as C, io, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+from volumetricinterp_amd import _lib, fitengine, synth
+from test_gpu_configs import _engine, CFG144
+out = {}
+ctx = _lib.get_context()
+_lib._sig("vi_eigvals_f64", C.c_int, _lib.VOIDP, C.c_int64, C.c_int32, _lib.VOIDP, _lib.VOIDP, _lib.VOIDP)
+rng = np.random.default_rng(3)
+for N in (144, 100):
+    B = 12
+    X = np.empty((B, N, N))
+    for i in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        lam = rng.uniform(0.1, 1., N) if i %% 2 else 10.0**rng.uniform(-40, 0, N) * rng.choice([-1, 1], N)
+        Mx = (Q * lam) @ Q.T
+        X[i] = 0.5 * (Mx + Mx.T)
+    dX, dl, ds = ctx.to_device(X), ctx.empty((B, N)), ctx.empty((B,), np.int32)
+    _lib.check(_lib.lib.vi_eigvals_f64(ctx.handle, B, N, dX.ptr, dl.ptr, ds.ptr), "vi_eigvals_f64")
+    out["lam%%d" %% N], out["sw%%d" %% N] = dl.download(), ds.download()
+m, ctx, eng, A, _ = _engine(CFG144, synth.GEOM_C2)
+P, T = A.shape[0], 12
+value, error = synth.synth_records(A, T, seed0=1000)
+res = eng.fit(error**-2., value, [P] * T)
+out["C"], out["cov"], out["chi"] = res["Coeffs"], res["Covariance"], res["chi_sq"]
+out["alpha"] = np.array([res["reg_params"][t]["curvature"] for t in range(T)])
+out["its"] = np.array([res["search"]["curvature"]["info"][t].get("iterations", -1) or -1 for t in range(T)])
+np.savez(sys.argv[1], **out)
+''' % (REPO_ROOT, REPO_ROOT))
+    got = {}
+    for mode in ('v1', 'v2'):
+        env = dict(os.environ)
+        env.pop('VINTERP_K3', None)
+        if mode == 'v1':
+            env['VINTERP_K3'] = 'v1'
+        o = str(tmp_path / ('out_%s.npz' % mode))
+        r = subprocess.run([sys.executable, str(script), o], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got[mode] = np.load(o)
+    assert (got['v1']['sw144'] > 5).any()
+    for k in got['v1'].files:
+        assert np.array_equal(got['v1'][k], got['v2'][k], equal_nan=True), k
+    assert np.isfinite(got['v2']['alpha']).sum() >= 8

@@ -21,6 +21,7 @@
 // A solve that the sweep cap ends before it converges makes the record leave with status 2: the host runs that record's
 // iteration itself (FitEngine: rotated-system solves that did not converge are solved again from X(alpha)).
 #include "vi_jacobi_device.h"
+#include "vi_jacobi_v2_device.h"
 #include "vi_gemm_device.h"
 #include "vi_exp10.h"
 
@@ -30,6 +31,7 @@
 size_t vi_jacobi_lds_bytes(int N);
 size_t vi_jacobi_log_bytes(int N, int max_sweeps);
 bool vi_jacobi_supported(int N);
+bool vi_jacobi_use_v2(int N);           // vi_jacobi.hip: the role-separated K3 serves this order
 double vi_floor_warm();                  // vi_fit.hip: absolute rotation floor of the rotated-system solves
 extern "C" int vi_max_sweeps(void);
 
@@ -156,8 +158,13 @@ __device__ __noinline__ void jacobi_system_call(unsigned char* lds_raw, int N, c
                                                 double rcond, double abs_floor, double* Cs, double2* logp, int max_sweeps,
                                                 int* sweeps_s, int* nround_s, unsigned long long* round_acc)
 {
-    jacobi_system<IT>(lds_raw, N, Xs, sc, ys, rcond, abs_floor, Cs, nullptr, logp, max_sweeps, sweeps_s, nullptr, 0, nround_s,
-                      round_acc);
+    // IT == 0: the role-separated kernel body (vi_jacobi_v2_device.h; blockDim = 64 + one thread per super-block)
+    if constexpr (IT == 0)
+        jacobi_system_v2(lds_raw, N, Xs, sc, ys, rcond, abs_floor, Cs, nullptr, logp, max_sweeps, sweeps_s, nullptr, 0, nround_s,
+                         round_acc);
+    else
+        jacobi_system<IT>(lds_raw, N, Xs, sc, ys, rcond, abs_floor, Cs, nullptr, logp, max_sweeps, sweeps_s, nullptr, 0, nround_s,
+                          round_acc);
 }
 
 // The move of a record's rotated system (vi_warm_rebase_f64's kernels in its order), out of line for the same reason.
@@ -192,7 +199,7 @@ __device__ __noinline__ void rebase_call(unsigned char* lds_raw, int N, const do
 }
 
 template <int IT>
-__global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
+__global__ __launch_bounds__(IT <= 1 ? 768 : 512) void k_brent_warm(
     int N, int64_t P, int ntask, double* D1, double* D2, double* yt, double* V, const double* __restrict__ AWA,
     const double* __restrict__ Rm, const double* __restrict__ ysrc, RebaseRule rr, double* __restrict__ VwW, double* __restrict__ VnW,
     const double* __restrict__ At, const double* __restrict__ W, const double* __restrict__ b,
@@ -389,6 +396,13 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_brent_warm(
 
 void brent_geometry(int N, int& threads, int& it)
 {
+    if (vi_jacobi_use_v2(N)) {                       // set-up wave + one thread per super-block (at least 512: the chi^2 pass)
+        const int Mv = ((N + 3) & ~3) / 4, nsbv = Mv * (Mv - 1) / 2;
+        it = 0;
+        threads = 64 + ((nsbv + 63) / 64) * 64;
+        if (threads < 512) threads = 512;
+        return;
+    }
     const int M = ((N + 3) & ~3) / 4;
     const int nsb = M * (M - 1) / 2;
     if (nsb <= 768) {
@@ -615,7 +629,8 @@ extern "C" int vi_brent_warm_f64(vi_ctx* c, int64_t ntask, int32_t N, int64_t P,
     // (vi_solve_timing: the launch counts among the eigen-solve launches - it is one, record after record)
     const int tslot = (int)(c->solve_launches % vi_ctx::NSOLVE_EV);
     if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[tslot][0], c->stream));
-    if (it <= 1) VI_B(1);
+    if (it == 0) VI_B(0);
+    else if (it <= 1) VI_B(1);
     else if (it <= 2) VI_B(2);
     else VI_B(3);
 #undef VI_B

@@ -64,6 +64,9 @@ __device__ unsigned long long g_rot_hist[32][2];
 #endif
 
 #include "vi_jacobi_device.h"
+#include "vi_jacobi_v2_device.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -81,6 +84,22 @@ __global__ __launch_bounds__(IT == 1 ? 768 : 512) void k_jacobi_solve(
                       abs_floor, C + sys * N, rank ? rank + sys : nullptr, rotlog + sys * log_stride, max_sweeps,
                       sweeps_out ? sweeps_out + sys : nullptr, lam_out ? lam_out + sys * N : nullptr, lam_raw,
                       nround_out ? nround_out + sys : nullptr, round_acc, conv_tol);
+}
+
+// The role-separated kernel (vi_jacobi_v2_device.h): blockDim = 64 (set-up wave) + one thread per super-block.
+__global__ __launch_bounds__(768) void k_jacobi_solve_v2(
+    int N, const double* __restrict__ X, const double* __restrict__ scl, const double* __restrict__ y,
+    const int* __restrict__ rec, double rcond, double abs_floor, double* __restrict__ C, int* __restrict__ rank,
+    double2* __restrict__ rotlog, int64_t log_stride, int max_sweeps, int* __restrict__ sweeps_out,
+    double* __restrict__ lam_out, int lam_raw, int* __restrict__ nround_out, unsigned long long* __restrict__ round_acc,
+    double conv_tol)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int64_t sys = blockIdx.x;
+    jacobi_system_v2(lds_raw, N, X + sys * (int64_t)N * N, scl ? scl[sys] : 1.0, y + (int64_t)(rec ? rec[sys] : sys) * N, rcond,
+                     abs_floor, C + sys * N, rank ? rank + sys : nullptr, rotlog + sys * log_stride, max_sweeps,
+                     sweeps_out ? sweeps_out + sys : nullptr, lam_out ? lam_out + sys * N : nullptr, lam_raw,
+                     nround_out ? nround_out + sys : nullptr, round_acc, conv_tol);
 }
 
 // Eigenvectors from the rotation log: V = J_1 J_2 ... J_K, so column k of V is the reverse replay applied to the unit
@@ -151,11 +170,32 @@ void jacobi_geometry(int N, int& threads, int& it)
 
 }  // namespace
 
+// The role-separated kernel serves the orders with one super-block per thread that leave room for the set-up wave in a
+// 768-thread workgroup, from 24 matches on (N = 93 ... 148: the benchmarked order 144 with 704 threads; below, the fixed cost of
+// its counters outweighs what it overlaps);
+// VINTERP_K3=v1 keeps the two-barrier kernel everywhere.  Same bits either way (tests/test_gpu_search_stages.py).
+bool vi_jacobi_use_v2(int N)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("VINTERP_K3");
+        forced = (e && !strcmp(e, "v1")) ? 1 : 0;
+    }
+    if (forced) return false;
+    int threads, it;
+    jacobi_geometry(N, threads, it);
+    const int M = ((N + 3) & ~3) / 4;
+    return it == 1 && M >= 24 && M <= 64 && threads + 64 <= 768;     // (from N = 93: measured -2 % at N = 100, -9 % at 144, +2 % at 32)
+}
+
+// LDS of a workgroup: the image, y x 2, the rotations, scratch - and for the role-separated kernel the rotations twice, the
+// mailbox, the counters and the destination table of the diagonal blocks
 size_t vi_jacobi_lds_bytes(int N)
 {
     const int Np = (N + 3) & ~3, M = Np / 4;
     const int nt = Np * (Np + 1) / 2;
-    const size_t b = (size_t)(nt + 2 * Np) * 8 + (size_t)4 * M * 16 + 16 * 8;
+    size_t b = (size_t)(nt + 2 * Np) * 8 + (size_t)4 * M * 16 + 16 * 8;
+    if (vi_jacobi_use_v2(N)) b += (size_t)4 * M * 16 + (size_t)4 * M * 8 + 16 + (size_t)14 * M * 4;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -210,6 +250,23 @@ int vi_jacobi_solve(vi_ctx* c, int64_t B, int N, const double* d_X, const double
 {
     int threads, it;
     jacobi_geometry(N, threads, it);
+    if (vi_jacobi_use_v2(N)) {
+        const size_t shm = vi_jacobi_lds_bytes(N);
+        VI_HIP(hipFuncSetAttribute((const void*)k_jacobi_solve_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        const int64_t ls = log_stride > 0 ? log_stride : jacobi_log_stride(N, max_sweeps);
+        const int slot = (int)(c->solve_launches % vi_ctx::NSOLVE_EV);
+        if (c->solve_timing) VI_HIP(hipEventRecord(c->evs[slot][0], c->stream));
+        hipLaunchKernelGGL(k_jacobi_solve_v2, dim3((unsigned)B), dim3(threads + 64), shm, c->stream, N, d_X, d_scl, d_y, d_rec, rcond,
+                           abs_floor, d_C, d_rank, (double2*)d_log, ls, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround,
+                           c->solve_timing ? c->d_rounds : nullptr, conv_tol);
+        VI_HIP(hipGetLastError());
+        if (c->solve_timing) {
+            VI_HIP(hipEventRecord(c->evs[slot][1], c->stream));
+            c->solve_launches += 1;
+            c->solve_systems += B;
+        }
+        return VI_OK;
+    }
 #define VI_J(IT) return launch_jacobi<IT>(c, threads, B, N, d_X, d_scl, d_y, d_rec, rcond, d_C, d_rank, d_log, max_sweeps, d_sweeps, d_lam, lam_raw, d_nround, abs_floor, log_stride, conv_tol)
     if (it <= 1) VI_J(1);
     if (it <= 2) VI_J(2);
