@@ -1,5 +1,7 @@
-"""Two builds of the library on the same systems: eigenvalues (vi_eigvals_f64) and sweeps bit for bit, and the time per launch.
-python tools/ab_jacobi_bits.py before.so after.so [N]   (each library is loaded in a process of its own)"""
+"""Two builds of the library - or one build with and without VINTERP_K3=v1 - on the same systems: eigenvalues (vi_eigvals_f64) and
+sweeps bit for bit, and the time per launch.
+python tools/ab_jacobi_bits.py before.so after.so [N ...]   (each library is loaded in a process of its own; a path given as
+"v1:lib.so" runs that library with VINTERP_K3=v1, i.e. the two-barrier kernel at every order)"""
 import ctypes as C
 import os
 import subprocess
@@ -53,11 +55,15 @@ if __name__ == '__main__':
         run(sys.argv[2], int(sys.argv[3]), sys.argv[4])
         sys.exit(0)
     a, b = sys.argv[1], sys.argv[2]
-    for N in ([int(sys.argv[3])] if len(sys.argv) > 3 else [144, 32, 12, 100, 160]):
+    for N in ([int(x) for x in sys.argv[3:]] if len(sys.argv) > 3 else [144, 32, 12, 100, 160]):
         res = []
         for k, lp in enumerate((a, b)):
             out = '/tmp/ab_%d_%d.npz' % (N, k)
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--one', lp, str(N), out])
+            env = dict(os.environ)
+            if lp.startswith('v1:'):
+                lp = lp[3:]
+                env['VINTERP_K3'] = 'v1'
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--one', lp, str(N), out], env=env)
             res.append(np.load(out))
         same = np.array_equal(res[0]['lam'], res[1]['lam']) and np.array_equal(res[0]['sw'], res[1]['sw'])
         print('N %3d: eigenvalues and sweeps of 64 systems %s; launch %.3f ms -> %.3f ms (sweeps max %d)'
