@@ -185,7 +185,9 @@ bool vi_jacobi_use_v2(int N)
     int threads, it;
     jacobi_geometry(N, threads, it);
     const int M = ((N + 3) & ~3) / 4;
-    return it == 1 && M >= 24 && M <= 64 && threads + 64 <= 768;     // (from N = 93: measured -2 % at N = 100, -9 % at 144, +2 % at 32)
+    static int minm = -1;
+    if (minm < 0) { const char* e2 = getenv("VINTERP_K3_MINM"); minm = e2 ? atoi(e2) : 24; if (minm < 3) minm = 3; }
+    return it == 1 && M >= minm && M <= 64 && threads + 64 <= 768;     // (from N = 93: measured -2 % at N = 100, -9 % at 144, +2 % at 32)
 }
 
 // LDS of a workgroup: the image, y x 2, the rotations, scratch - and for the role-separated kernel the rotations twice, the
