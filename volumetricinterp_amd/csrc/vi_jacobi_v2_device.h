@@ -19,9 +19,10 @@
 //     workgroup barrier per round (rotations published, blocks fetched) take the place of the two barriers;
 //   * the two roles run the same loop skeleton as two separate loops, so that each gets a register allocation of its own: 155
 //     VGPRs, nothing spilled (one loop with role branches spilled the sixteen store addresses: 3500 cycles per round).
-// Measured (MI355X, 64 cold systems of 25 sweeps): N = 144 4.19 -> 3.80 ms (-9 %), N = 100 -2 %, N = 32 +2 %: used from 24 matches on
-// (vi_jacobi_use_v2).  Stamps (tools/exp_stamps_v2.py): set-up wave 1770 + copies 500 + hand-over 570 per round, update waves
-// fetch 590 + update 2100 + stores 290 - the two paths balanced at ~3400 (stamped) where the two-barrier kernel takes 4300.
+// Measured (MI355X, 64 cold systems of 25 sweeps): N = 144 4.22 -> 3.70 ms (-12.5 %), -4 ... -12 % over N = 93 ... 149, break-even at
+// N = 72, +2 % at N = 32: used from 24 matches on (vi_jacobi_use_v2).  Stamps (tools/exp_stamps_v2.py): set-up wave 1830 + copies 240
+// + hand-over 590 per round, update waves fetch 660 + update 2200 + stores 280 - the update waves the longer path at ~3360 stamped
+// cycles where the two-barrier kernel has 4300 serial ones.
 // What did NOT work on the way is under tools/experiments/ (reading the diagonal planes back from LDS; one loop for both roles;
 // holding the stores back until the mailbox is read).
 #pragma once
@@ -38,6 +39,7 @@ __device__ __forceinline__ void lds_signal(int* w, int n)
 }
 // Wave-uniform bounded wait (~2^22 polls: seconds): a counter that never arrives ends the wait instead of hanging the GPU;
 // the solve then reports "not converged" through `bad`.
+template <bool SLEEP = true>
 __device__ __forceinline__ void lds_wait(int* w, int target, int& bad)
 {
     const int tgt = __builtin_amdgcn_readfirstlane(target);
@@ -47,7 +49,7 @@ __device__ __forceinline__ void lds_wait(int* w, int target, int& bad)
         const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (v >= tgt) break;
         if (++spins > (1 << 22)) { bad = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
+        if (SLEEP) __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
 }
@@ -231,15 +233,24 @@ __device__ __forceinline__ void jacobi_system_v2(
                 VI_STAMP(0);
                 __syncthreads();                      // rotations published, blocks fetched
                 VI_STAMP(1);
-                // ---- the LDS copies of my diagonal block and right-hand side, at their permuted places (the termination test and
-                //      the final solve read them; four of the block's elements land in an off-diagonal block that an update
-                //      thread fetches next round - hence after the barrier, and counted among the stores of the round)
+                // ---- what LDS needs of my diagonal block: four of its elements land in an off-diagonal block that an update thread
+                //      fetches next round (hence after the barrier, and counted among the stores of the round); the rest and y
+                //      are only read by the sweep-end test and the final solve
                 if (tid < M) {
+                    if (r == m - 1) {
+                        // last round of the sweep: the whole block and y (the sweep-end test and the final solve read them)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        yv[(ycur ^ 1) * Np + (intra ? 4 * tid + p : yd[p])] = yy[p];
+                        for (int p = 0; p < 4; ++p) {
+                            yv[(ycur ^ 1) * Np + yd[p]] = yy[p];
 #pragma unroll
-                        for (int q = p; q < 4; ++q) A[intra ? dg + j10(p, q) * M + tid : dd[j10(p, q)]] = d[p][q];
+                            for (int q = p; q < 4; ++q) A[dd[j10(p, q)]] = d[p][q];
+                        }
+                    } else if (!intra) {
+                        // any other round: only the four elements between my two units - they become part of an off-diagonal block
+                        A[dd[j10(0, 2)]] = d[0][2];
+                        A[dd[j10(0, 3)]] = d[0][3];
+                        A[dd[j10(1, 2)]] = d[1][2];
+                        A[dd[j10(1, 3)]] = d[1][3];
                     }
                 }
                 VI_STAMP(2);
@@ -267,7 +278,7 @@ __device__ __forceinline__ void jacobi_system_v2(
                     yy[2] = ll ? oy0 : nyv0;
                     yy[3] = ll ? oy1 : nyv1;
                     VI_STAMP(3);
-                    lds_wait(sync, tgt_mb + M, bad);
+                    lds_wait<false>(sync, tgt_mb + M, bad);      // (one wave polling: no pause between polls)
                     if (tid < M) {
                         d[0][2] = d[2][0] = mb[tid];
                         d[0][3] = d[3][0] = mb[M + tid];
@@ -310,7 +321,10 @@ __device__ __forceinline__ void jacobi_system_v2(
                     for (int e = 0; e < 16; ++e) b[e] = A[ksrc + e * nsb];
                 }
                 VI_STAMP(0);
-                __syncthreads();                      // rotations published, blocks fetched
+                // The barrier publishes wave 0's rotations; my own outstanding LDS operations are the block loads just issued -
+                // nobody else depends on them, so they stay in flight across the barrier (a plain s_barrier: __syncthreads() would
+                // first wait for them) and are waited for where the update uses them.
+                asm volatile("s_barrier" ::: "memory");
                 VI_STAMP(1);
                 // ---- S_ab <- R_a^T S_ab R_b, stored at the permuted slots; wave 1 - the blocks the next set-up waits for - first
                 if (tid < 128 && !intra) __builtin_amdgcn_s_setprio(3);
