@@ -404,11 +404,13 @@ def run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, 
 
     def kernel_ms(fn, reps=5):
         best = float('inf')
-        for _ in range(reps):
-            fn()
-            kms = C.c_double(0.)                   # HIP events right around the evaluation kernel launches
-            _lib.check(_lib.lib.vi_eval_kernel_ms(ctx.handle, C.byref(kms)), 'vi_eval_kernel_ms')
-            best = min(best, kms.value)
+        ctx.eval_timing(True)                      # HIP events right around the evaluation kernel launches: off by default
+        try:
+            for _ in range(reps):
+                fn()
+                best = min(best, ctx.eval_kernel_ms())
+        finally:
+            ctx.eval_timing(False)
         return best
 
     # ---- the evaluation kernel on its own (not part of `value`): with and without the hull pass ---------------------

@@ -161,8 +161,11 @@ int  vi_eval_resident_f64(vi_model* model, int64_t Q, int64_t T, const double* d
  * BASELINE configs[4] sweeps against the 1e-6 tolerance.  Orders with an fp32 kernel: (MAXL, MAXK) = (6,4), (2,8), (12,8);
  * others return VI_ERR_UNSUPPORTED from vi_eval_f64 while the flag is set. */
 int  vi_model_set_eval_precision(vi_model* model, int32_t chain_f32);
-/* device time (ms) of the evaluation kernel launches of the last vi_eval_f64 call on this context, from HIP
- * events recorded on the context's stream around them (the preparation kernels are excluded) */
+/* device time (ms) of the evaluation kernel launches of the last vi_eval_f64 / vi_eval_resident_f64 call on this context, from
+ * HIP events recorded on the context's stream around them (the preparation kernels are excluded).  The events are recorded
+ * only while vi_ctx_set_eval_timing(ctx, 1) is in force (default: off - the pair costs a 0.2 ms call about 7 us);
+ * vi_eval_kernel_ms fails with VI_ERR_ARG while it is off or before a call has been timed. */
+int  vi_ctx_set_eval_timing(vi_ctx* ctx, int32_t on);
 int  vi_eval_kernel_ms(vi_ctx* ctx, double* ms);
 /* device time of the eigen-solve kernel launches (the kernel the fit spends its time in), from one HIP event pair
  * per launch on the context's stream.  enable = 1 starts / resets recording, 0 stops it, -1 only reads; the

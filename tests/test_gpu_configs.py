@@ -633,6 +633,11 @@ def test_c4_fp32_chain_sweep(capsys, maxk, maxl, cap):
     C1 = np.random.default_rng(5).standard_normal((1, N)) / np.sqrt(np.sum(A * A, axis=0))
     dC, dout = ctx.to_device(C1), ctx.empty((1, Q))
 
+    # the events around the evaluation kernel are off by default (they cost a 0.2 ms call ~7 us): reading the time says so
+    ctx.eval_timing(False)
+    with pytest.raises(_lib.VinterpError, match='vi_ctx_set_eval_timing'):
+        ctx.eval_kernel_ms()
+    ctx.eval_timing(True)
     def run():
         best = 1e9
         for _ in range(3):
@@ -646,6 +651,7 @@ def test_c4_fp32_chain_sweep(capsys, maxk, maxl, cap):
     lo, t32 = run()
     m.set_eval_precision('f64')
     again, _ = run()
+    ctx.eval_timing(False)
     assert np.array_equal(again, ref)
     err = rel(lo, ref)
     worst = float(np.max(np.abs(lo - ref)) / np.max(np.abs(ref)))

@@ -69,11 +69,12 @@ def test_hull_mask_is_independent_of_the_coefficients():
 
 
 def test_hull_mask_pass_on_surface_points_ragged_sizes_and_nonfinite_coordinates():
-    """The mask pass (k_hull_mask: fp32 half-space prefilter with scalar-loaded planes, exact fp64 test of the points within
-    the band of the surface spread over the lanes of a wave) against the definition in NumPy fp64 -
+    """The mask pass (k_hull_mask_mx: plane distances as fp16-split products on the matrix cores, exact fp64 test of the points
+    within the band of the surface spread over the lanes of a wave) against the definition in NumPy fp64 -
     inside <=> max_f (n_f . x + d_f) <= tol (estimate.py:153-178) - on points chosen to sit ON the hull (its own vertices,
     which the fp32 pass cannot decide), next to it (geodetic blends of neighbouring vertices), on query sizes that are not
-    multiples of the 2048 points of a workgroup, and on non-finite coordinates (outside)."""
+    multiples of the 1024 points of a workgroup, on non-finite coordinates (outside), on points and facet lists outside the
+    prefilter's range."""
     from scipy.spatial import ConvexHull
     from volumetricinterp_amd import synth
     from volumetricinterp_amd.estimate import Estimate, hull_equations
@@ -98,7 +99,7 @@ def test_hull_mask_pass_on_surface_points_ragged_sizes_and_nonfinite_coordinates
     expect = d <= tol
     decided = np.abs(d - tol) > 1e-6                # the device's ECEF differs from NumPy's in the last bits (~1e-9 m)
     assert (~decided).sum() < 400 and 200 < expect.sum() < len(expect) - 200
-    for Q in (len(qlat), 1, 63, 2049, 5000):
+    for Q in (len(qlat), 1, 63, 1025, 2049, 5000):
         got = es.check_hull(qlat[:Q], qlon[:Q], qalt[:Q])
         assert np.array_equal(got[decided[:Q]], expect[:Q][decided[:Q]]), Q
     # the hull's own vertices are inside (Qhull's coplanar points, estimate.py:174-176) - all of them in the fp64 band
@@ -116,6 +117,76 @@ def test_hull_mask_pass_on_surface_points_ragged_sizes_and_nonfinite_coordinates
     keep = np.ones(300, dtype=bool)
     keep[[5, 70, 131]] = False
     assert np.array_equal(got[keep], ref[keep])
+    # points the fp16 planes of the matrix-core pass do not reach (further than 16 000 km from its reference point: the far side
+    # of the Earth, 20 000 km up) and angles beyond the range of its own sine / cosine (longitude + 2000 turns): decided by the
+    # fp64 test, same answers, neighbours undisturbed
+    far = qlat[:300].copy(), qlon[:300].copy(), qalt[:300].copy()
+    far[0][7], far[1][7], far[2][7] = -75., 80., 9.0e5
+    far[2][40] = 2.0e7
+    far[1][100:164] = far[1][100:164] + 360. * 2000.
+    got = es.check_hull(*far)
+    assert not got[7] and not got[40]
+    keep = np.ones(300, dtype=bool)
+    keep[[7, 40]] = False
+    keep[100:164] = np.abs(d[100:164] - tol) > 1e-3               # (the shifted longitudes move a point by ~1e-5 m)
+    assert np.array_equal(got[keep], ref[keep])
+    # the facet list as the C-ABI takes it: normals that are not unit vectors (every equation and the tolerance times 3, then
+    # times 1e-3: the pass scales by the longest normal), a list with a non-finite entry (the definition puts every point
+    # outside: NaN <= tol is false), offsets beyond the fp16 range (every point through the fp64 test)
+    import ctypes as C
+    from volumetricinterp_amd import _lib
+    m, ctx = es.model, es.model.ctx
+    Q = len(qlat)
+    dq = [ctx.to_device(np.ascontiguousarray(a)) for a in (qlat, qlon, qalt)]
+    dC, dout = ctx.to_device(np.zeros((1, m.nbasis))), ctx.empty((1, Q))
+
+    def mask_of(e, t):
+        de = ctx.to_device(np.ascontiguousarray(e))
+        _lib.check(_lib.lib.vi_eval_f64(m.handle(), Q, dq[0].ptr, dq[1].ptr, dq[2].ptr, 1, dC.ptr, de.ptr, len(e), float(t), dout.ptr),
+                   'vi_eval_f64')
+        return np.isfinite(dout.download()[0])
+    base = mask_of(eq, tol)
+    assert np.array_equal(base[decided], expect[decided])
+    for f in (3., 1e-3):
+        assert np.array_equal(mask_of(eq * f, tol * f)[decided], expect[decided]), f
+    bad_eq = eq.copy()
+    bad_eq[17, 1] = np.nan
+    assert not mask_of(bad_eq, tol).any()
+    shifted = eq.copy()
+    shifted[:, 3] -= 1e8
+    assert mask_of(shifted, tol).all()
+    shifted[:, 3] += 2e8
+    assert not mask_of(shifted, tol).any()
+
+
+def test_packed_fp32_hull_pass_gives_the_same_mask(tmp_path):
+    """VINTERP_HULL=fp32 (read once per process: a subprocess) runs the packed-fp32 plane loop of rounds 2-3 (k_hull_mask)
+    instead of the matrix-core pass; both hand their band to the same fp64 test, so the masks are the same bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from scipy.spatial import ConvexHull\n"
+        "from volumetricinterp_amd import synth\n"
+        "from volumetricinterp_amd.estimate import Estimate\n"
+        "from volumetricinterp_amd.geodesy import geodetic2ecef\n"
+        "lat, lon, alt = synth.beams(*synth.GEOM_C2, seed=0)\n"
+        "R = np.array(geodetic2ecef(lat, lon, alt)).T\n"
+        "es = Estimate.from_arrays(np.zeros((1, 144)), None, synth.unix_times(1), R[ConvexHull(R).vertices], %r)\n"
+        "g = synth.query_grid(40)\n"
+        "np.save(sys.argv[1], es.check_hull(*g))\n" % (root, CFG))
+    masks = []
+    for mode in ('', 'fp32'):
+        env = dict(os.environ)
+        env.pop('VINTERP_HULL', None)
+        if mode:
+            env['VINTERP_HULL'] = mode
+        out = str(tmp_path / ('mask_%s.npy' % (mode or 'mx')))
+        subprocess.run([sys.executable, '-c', script, out], check=True, env=env, timeout=300)
+        masks.append(np.load(out))
+    assert 0.2 < masks[0].mean() < 0.8
+    assert np.array_equal(masks[0], masks[1])
 
 
 def test_record_fit_is_independent_of_its_batch(tmp_path):

@@ -35,8 +35,8 @@ def call_ms(e):
 
 
 base, _ = call_ms(None)
-inside = eq.copy(); inside[:, 3] -= 1e7
-outside = eq.copy(); outside[:, 3] += 1e7
+inside = eq.copy(); inside[:, 3] -= 2e6       # (2000 km: the fp16 planes of k_hull_mask_mx reach 16 000 km from c0)
+outside = eq.copy(); outside[:, 3] += 2e6
 for name, e in (('460 facets as they are', eq), ('16 facets', eq[:16]), ('460 facets, all points deep inside', inside),
                 ('460 facets, all points outside', outside), ('920 facets, all inside', np.vstack([inside, inside]))):
     ms, frac = call_ms(e)

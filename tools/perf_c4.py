@@ -20,6 +20,7 @@ def main():
     chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 128
     m = Model(io.StringIO(CFG % (4, 6)))
     ctx = m.ctx
+    ctx.eval_timing(True)                          # vi_eval_kernel_ms below
     h = m.handle()
     g = synth.query_grid(n)
     Q = g[0].size

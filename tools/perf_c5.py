@@ -21,6 +21,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     m = Model(io.StringIO(CFG))
     ctx = m.ctx
+    ctx.eval_timing(True)                          # vi_eval_kernel_ms below
     lat, lon, alt = synth.beams(64, 200, seed=0)
     P, N = lat.size, m.nbasis
     d = [ctx.to_device(a) for a in (lat, lon, alt)]

@@ -101,6 +101,7 @@ _sig('vi_eval_f64_host', C.c_int, VOIDP, I64, c_double_p, c_double_p, c_double_p
      C.c_int32, C.c_double, c_double_p)
 
 _sig('vi_eval_kernel_ms', C.c_int, VOIDP, c_double_p)
+_sig('vi_ctx_set_eval_timing', C.c_int, VOIDP, C.c_int32)
 _sig('vi_model_set_eval_precision', C.c_int, VOIDP, C.c_int32)
 _sig('vi_host_alloc', C.c_int, C.c_size_t, C.POINTER(VOIDP))
 _sig('vi_host_free', C.c_int, VOIDP)
@@ -112,7 +113,7 @@ _sig('vi_rccl_init', C.c_int, VOIDP, C.c_int, C.c_int, C.c_char_p)
 _sig('vi_rccl_bcast_f64', C.c_int, VOIDP, VOIDP, I64, C.c_int)
 _sig('vi_rccl_destroy', C.c_int, VOIDP)
 
-EXPORTS = ['vi_eval_basis_f64', 'vi_eval_resident_f64', 'vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
+EXPORTS = ['vi_eval_basis_f64', 'vi_eval_resident_f64', 'vi_host_alloc', 'vi_host_free', 'vi_model_set_eval_precision', 'vi_solve_rounds', 'vi_grad_basis_f64', 'vi_eval_grad_f64', 'vi_eval_err_f64', 'vi_eval_kernel_ms', 'vi_ctx_set_eval_timing', 'vi_solve_timing', 'vi_rccl_unique_id', 'vi_rccl_init', 'vi_rccl_bcast_f64', 'vi_rccl_destroy', 'vi_abi_version', 'vi_device_count', 'vi_ctx_create', 'vi_ctx_destroy', 'vi_ctx_sync', 'vi_last_error',
            'vi_dmalloc', 'vi_dfree', 'vi_h2d', 'vi_d2h', 'vi_d2h_side_mark', 'vi_d2h_side', 'vi_dmemset', 'vi_mem_info', 'vi_timer_start', 'vi_timer_stop_ms',
            'vi_model_create', 'vi_model_destroy', 'vi_basis_f64', 'vi_transform_f64', 'vi_eval_f64',
            'vi_eval_f64_host']
@@ -142,6 +143,15 @@ class Context:
 
     def sync(self):
         check(lib.vi_ctx_sync(self.handle), 'vi_ctx_sync')
+
+    def eval_timing(self, on):
+        """HIP events around the evaluation kernels of every call (read with eval_kernel_ms); off by default."""
+        check(lib.vi_ctx_set_eval_timing(self.handle, 1 if on else 0), 'vi_ctx_set_eval_timing')
+
+    def eval_kernel_ms(self):
+        ms = C.c_double(0.)
+        check(lib.vi_eval_kernel_ms(self.handle, C.byref(ms)), 'vi_eval_kernel_ms')
+        return ms.value
 
     def mem_info(self):
         """(free, total) bytes of the device."""

@@ -202,11 +202,22 @@ extern "C" int vi_timer_stop_ms(vi_ctx* c, double* ms)
     return VI_OK;
 }
 
+// HIP events around the evaluation kernel launches of every vi_eval_f64 / vi_eval_resident_f64 call on this context: off by
+// default (the two records cost a call of 0.2 ms about 7 us), on for whoever reads vi_eval_kernel_ms
+extern "C" int vi_ctx_set_eval_timing(vi_ctx* c, int32_t on)
+{
+    VI_REQUIRE(c, "null argument");
+    c->evk_enabled = on != 0;
+    if (!c->evk_enabled) c->evk_valid = false;
+    return VI_OK;
+}
+
 // duration of the evaluation kernel launches of the last vi_eval_f64 call (HIP events recorded on the
 // context's stream right around them, excluding the coefficient / hull preparation kernels)
 extern "C" int vi_eval_kernel_ms(vi_ctx* c, double* ms)
 {
     VI_REQUIRE(c && ms, "null argument");
+    VI_REQUIRE(c->evk_enabled, "evaluation timing is off on this context: vi_ctx_set_eval_timing(ctx, 1) first");
     VI_REQUIRE(c->evk_valid, "no vi_eval_f64 call has been timed on this context");
     VI_HIP(hipEventSynchronize(c->evk1));
     float f = 0.f;

@@ -293,6 +293,7 @@ struct EvalSink {
 // non-finite coordinates are outside.  The byte mask is reused by every timestep tile of the evaluation.
 constexpr float HULL_BAND = 4.0f;
 constexpr float HULL_BAND_REL = 1.0e-6f;
+constexpr int HULL_HDR = 8;          // doubles in front of the facet equations: c0 (3), s, offmax, 3 spare
 
 constexpr int HULL_PP = 8;          // points per thread: every facet fetched serves eight points
 constexpr int HULL_PAD = 16;        // the fp32 facet list is padded to a multiple of 16 with repeats of facet 0
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_hull_mask(int64_t Q, const double*
                                                      unsigned char* __restrict__ mask)
 {
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const float4* __restrict__ pl = reinterpret_cast<const float4*>(hull + 4 + 4 * (size_t)F);
+    const float4* __restrict__ pl = reinterpret_cast<const float4*>(hull + HULL_HDR + 4 * (size_t)F);
     const int Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
     const int64_t q0 = (int64_t)blockIdx.x * (BLOCK * HULL_PP) + threadIdx.x;      // points q0 + u * BLOCK
     const double c0x = hull[0], c0y = hull[1], c0z = hull[2];
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_hull_mask(int64_t Q, const double*
     // (a lane running all F facets alone - F dependent scalar loads - held its whole wave for longer than the fp32 pass of
     // the entire grid takes: 150 us measured against 95 us with every point deep inside the hull)
     const int lane = threadIdx.x & 63;
-    const double* __restrict__ eq = hull + 4;
+    const double* __restrict__ eq = hull + HULL_HDR;
 #pragma unroll 1
     for (int u = 0; u < HULL_PP; ++u) {
         const int64_t q = q0 + (int64_t)u * BLOCK;
@@ -403,23 +404,315 @@ __global__ __launch_bounds__(BLOCK, 4) void k_hull_mask(int64_t Q, const double*
     }
 }
 
-// hullbuf <- [c0][eq][float4 facets]; c0 = foot of the origin's perpendicular on facet 0 (a point of the hull surface)
-__global__ void k_prep_hull(int F, const double* __restrict__ eq, double* __restrict__ hullbuf)
+// ---- the hull pass on the matrix cores (round 4) -------------------------------------------------------------------------
+// The plane distances of 32 points from 32 facets are ONE v_mfma_f32_32x32x16_f16: every coordinate (relative to c0, in units
+// of HULL_UNIT metres) and every normal component (times HULL_NSCALE) is split into two halves hi + lo (22 bits together), and
+// the sixteen k-slots of the instruction hold the four cross products of the three components plus the plane offset:
+//      k     0    1    2    3    4    5    6    7  |  8    9    10   11   12    13    14 15
+//  A  facet  nxh  nyh  nzh  nxl  nyl  nzl  nxh  nyh |  nzh  nxl  nyl  nzl  offh  offl  0  0
+//  B  point  xh   yh   zh   xh   yh   zh   xl   yl  |  zl   xl   yl   zl   1024  1024  0  0
+// (lanes 0-31 carry k 0-7 of row / column lane, lanes 32-63 k 8-15: cdna4 32x32x16 operand map).  The products of two halves
+// are exact in fp32; what is lost is the split (2^-22 of |x|, |n|, |off| each), the flush of a subnormal lo half (6e-8 |x|)
+// and the fp32 accumulation of sixteen terms (<= 16 x 2^-23 of (|x - c0| + |off|)): together < 2.5e-6 (|x - c0| + max |off|),
+// covered by the band HULL_BAND + HULL_MX_REL (|x - c0| + max |off|), inside which a point repeats the test in fp64 - the
+// mask is the fp64 definition's whatever the prefilter does inside its band.  The result column is the lane's point and the
+// sixteen registers are sixteen facets, so the maximum over the facets is eight v_max3_f32 per tile and lane and one
+// v_permlane32_swap at the end.  Measured (tools/microbench/mfma_max3_overlap.hip): 53 cycles per 1024 distances and SIMD with
+// zero operands, 74 with real ones - the shader clock drops from 2.3 to 1.6 GHz under the load, the loop is power-bound -
+// against ~190 of the packed-fp32 loop (k_hull_mask); 128^3 points x 460 facets: 88 -> 46 us over the call without a hull.
+// Normals longer than 1 are scaled down by s = max |n| (Qhull's are unit vectors: s = 1), points further than HULL_FAR from c0
+// and lists with a non-finite entry or an offset beyond the fp16 range go to the fp64 test as they are.
+constexpr float HULL_UNIT = 256.0f;          // metres per unit of the fp16 coordinates: 65504 units = 16 769 km
+constexpr float HULL_NSCALE = 1024.0f;       // the unit normal's components times this: the lo half stays a normal fp16 number
+constexpr float HULL_FAR = 1.6e7f;           // metres from c0 beyond which a point skips the fp16 prefilter
+constexpr float HULL_MX_REL = 4.0e-6f;
+constexpr int HULL_MX_PP = 4;                // points per thread = eight 32-point groups per wave and facet tile
+
+__device__ __forceinline__ unsigned hull_split(float v)          // (hi, lo) halves of v packed: hi in bits 0-15
+{
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+
+// sin and cos for the prefilter's geodetic -> ECEF: Cody-Waite reduction by pi/2 in two pieces (exact for |x| < 1e4: k has 13
+// bits) and the two kernels of fdlibm on |r| <= pi/4; 2.2e-16 absolute against libm on 2e7 arguments (a third of the
+// instructions of the library's sincos, which carries the Payne-Hanek path for huge arguments).  Only the prefilter uses it - the
+// points within the band are decided from the library's values, like the evaluation kernels' geometry.
+__device__ __forceinline__ void hull_sincos(double x, double& sn, double& cs)
+{
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double sr = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
+// geodetic2ecef (vi_sph_device.h) with hull_sincos; false when an angle is outside the range of its reduction (or NaN)
+__device__ __forceinline__ bool hull_geodetic2ecef(double lat, double lon, double alt, double& X, double& Y, double& Z)
+{
+    const double la = lat * DEG2RAD, lo = lon * DEG2RAD;
+    double sl, cl, so, co;
+    hull_sincos(la, sl, cl);
+    hull_sincos(lo, so, co);
+    const double a2 = WGS84_A * WGS84_A, b2 = WGS84_B * WGS84_B;
+    const double Nn = a2 / sqrt(a2 * cl * cl + b2 * sl * sl);
+    const double ba = WGS84_B / WGS84_A;
+    X = (Nn + alt) * cl * co;
+    Y = (Nn + alt) * cl * so;
+    Z = (Nn * (ba * ba) + alt) * sl;
+    return fabs(la) < 1.0e4 && fabs(lo) < 1.0e4;
+}
+
+typedef float hull_f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float hull_max16(const hull_f16v& c, float d)       // max(d, the sixteen results): eight v_max3_f32
+{
+    const float t0 = fmaxf(fmaxf(c[0], c[1]), c[2]), t1 = fmaxf(fmaxf(c[3], c[4]), c[5]), t2 = fmaxf(fmaxf(c[6], c[7]), c[8]),
+                t3 = fmaxf(fmaxf(c[9], c[10]), c[11]), t4 = fmaxf(fmaxf(c[12], c[13]), c[14]), t5 = fmaxf(fmaxf(c[15], d), t0),
+                t6 = fmaxf(fmaxf(t1, t2), t3);
+    return fmaxf(fmaxf(t4, t5), t6);
+}
+
+template <int PP>
+__global__ __launch_bounds__(BLOCK, 4) void k_hull_mask_mx(int64_t Q, const double* __restrict__ lat,
+                                                           const double* __restrict__ lon, const double* __restrict__ alt,
+                                                           const double* __restrict__ hull, int F, double tol,
+                                                           unsigned char* __restrict__ mask)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
+    const int T = (F + 31) / 32;
+    const u4* __restrict__ tiles = reinterpret_cast<const u4*>(hull + HULL_HDR + 4 * (size_t)F) + (Fp + 4);
+    const int lane = threadIdx.x & 63;
+    const int64_t q0 = (int64_t)blockIdx.x * (BLOCK * PP) + threadIdx.x;           // points q0 + u * BLOCK
+    const double c0x = hull[0], c0y = hull[1], c0z = hull[2];
+    const float s = (float)hull[3];
+    const float offmax = (float)hull[4];                                         // max |n . c0 + d| / s; inf: no prefilter
+    // geodetic -> ECEF of the thread's PP points, unrolled: their 3 PP loads are in flight together (one after the other a
+    // wave waited out a memory latency per point: the pass reads 24 B a point, 50 MB for 128^3).  thr < 0 marks a point the
+    // prefilter does not judge (non-finite, far away, angle beyond the range of hull_sincos).
+    // The B operands: lanes 0-31 hold k 0-7 of their column, lanes 32-63 k 8-15; one swap of the upper half of one register
+    // with the lower half of another makes a register of each of the two groups a 64-lane set of points consists of.
+    unsigned Bf[2 * PP][4];
+    float thr[PP];
+    double qlat[PP], qlon[PP], qalt[PP];
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+        const int64_t q = q0 + (int64_t)u * BLOCK;
+        const int64_t qc = q < Q ? q : Q - 1;
+        qlat[u] = lat[qc];
+        qlon[u] = lon[qc];
+        qalt[u] = alt[qc];
+    }
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+        double X, Y, Z;
+        const bool inrange = hull_geodetic2ecef(qlat[u], qlon[u], qalt[u], X, Y, Z);
+        float vx = (float)((X - c0x) * (1.0 / HULL_UNIT)), vy = (float)((Y - c0y) * (1.0 / HULL_UNIT)),
+              vz = (float)((Z - c0z) * (1.0 / HULL_UNIT));
+        const float r = HULL_UNIT * sqrtf(vx * vx + vy * vy + vz * vz);
+        const bool ok = inrange && r < HULL_FAR;                                 // false for NaN / inf coordinates too
+        if (!ok) vx = vy = vz = 0.0f;
+        const unsigned sx = hull_split(vx), sy = hull_split(vy), sz = hull_split(vz);
+        thr[u] = ok ? s * (HULL_BAND + HULL_MX_REL * (r + offmax)) : -1.0f;
+        const unsigned p0 = (sx & 0xffffu) | (sy << 16);                         // (xh, yh)
+        const unsigned p1 = (sz & 0xffffu) | (sx & 0xffff0000u);                 // (zh, xl)
+        const unsigned p2 = (sy >> 16) | (sz & 0xffff0000u);                     // (yl, zl)
+        const unsigned lo[4] = {p0,                                              // (xh, yh)
+                                (p1 & 0xffffu) | (p0 << 16),                     // (zh, xh)
+                                (p0 >> 16) | (p1 << 16),                         // (yh, zh)
+                                (p1 >> 16) | (p2 << 16)};                        // (xl, yl)
+        const unsigned hi[4] = {(p2 >> 16) | (p1 & 0xffff0000u),                 // (zl, xl)
+                                p2,                                              // (yl, zl)
+                                0x64006400u,                                     // (1024, 1024)
+                                0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const auto w = __builtin_amdgcn_permlane32_swap(lo[j], hi[j], false, false);
+            Bf[2 * u][j] = w[0];                    // lanes 0-31: lo of their own point; 32-63: hi of the point of lane - 32
+            Bf[2 * u + 1][j] = w[1];                // lanes 0-31: lo of the point of lane + 32; 32-63: hi of their own
+        }
+    }
+    float dmax[2 * PP];
+#pragma unroll
+    for (int g = 0; g < 2 * PP; ++g) dmax[g] = -3.0e38f;
+    const float cs = s * (HULL_UNIT / HULL_NSCALE);                              // accumulator units -> the equations' units
+    const float tolf = (float)tol;
+    u4 An = tiles[lane];
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const u4 A = An;
+        An = tiles[(size_t)(t + 1 < T ? t + 1 : t) * 64 + lane];
+        // Two accumulators by hand: the product of group g + 1 is issued before the maxima of group g are taken.  Left to the
+        // compiler the loop is product -> wait -> eight maxima -> next product on ONE accumulator, 85 cycles per product
+        // and SIMD at four waves against 53 this way (tools/microbench/mfma_max3_overlap.hip).  The products are inline
+        // assembly, so the wait between a matrix-core write and a vector read of it is ours to keep: s_nop 15 (16 wait
+        // states; the 8-pass product needs 12) tied to the accumulator in front of its first use.
+        f16v pa, pb;
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(pa) : "v"(A), "v"((u4){Bf[0][0], Bf[0][1], Bf[0][2], Bf[0][3]}));
+#pragma unroll
+        for (int g = 0; g < 2 * PP; g += 2) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
+                         : "=v"(pb) : "v"(A), "v"((u4){Bf[g + 1][0], Bf[g + 1][1], Bf[g + 1][2], Bf[g + 1][3]}));
+            asm volatile("s_nop 15" : "+v"(pa));
+            dmax[g] = hull_max16(pa, dmax[g]);
+            if (g + 2 < 2 * PP)
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
+                             : "=v"(pa) : "v"(A), "v"((u4){Bf[g + 2][0], Bf[g + 2][1], Bf[g + 2][2], Bf[g + 2][3]}));
+            asm volatile("s_nop 15" : "+v"(pb));
+            dmax[g + 1] = hull_max16(pb, dmax[g + 1]);
+        }
+        if ((t & (t + 1)) == 0 && t + 1 < T) {
+            // after tiles 0, 1, 3, 7, ...: a point is outside as soon as ONE facet says so - leave when every point of the
+            // wave is decided (the host hands the facets over in greedy-cover order: the first tile decides 98 % of them)
+            float slack = 3.0e38f;
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const auto w = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, dmax[2 * u]),
+                                                                __builtin_bit_cast(unsigned, dmax[2 * u + 1]), false, false);
+                const unsigned w0 = w[0], w1 = w[1];                  // (a bit_cast of w[1] itself reads w[0]: through scalars)
+                const float dm = cs * fmaxf(__uint_as_float(w0), __uint_as_float(w1));
+                slack = fminf(slack, thr[u] < 0.0f ? 3.0e38f : dm - thr[u]);
+            }
+            if (__all(slack > tolf)) break;
+        }
+    }
+    unsigned inbits = 0, border = 0;
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+        // lanes 0-31: the point's two partial maxima are dmax[2u] of this lane and of lane + 32; lanes 32-63: dmax[2u + 1]
+        const auto w = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, dmax[2 * u]),
+                                                        __builtin_bit_cast(unsigned, dmax[2 * u + 1]), false, false);
+        const unsigned w0 = w[0], w1 = w[1];                  // (a bit_cast of w[1] itself reads w[0]: through scalars)
+        const float dm = cs * fmaxf(__uint_as_float(w0), __uint_as_float(w1));
+        const float bd = thr[u];
+        if (bd < 0.0f || !(fabsf(dm - tolf) > bd)) border |= 1u << u;             // not judged, or within the band (NaN too)
+        else if (dm < tolf) inbits |= 1u << u;                                    // inside
+    }
+    // Points within the band: the exact fp64 test, one point at a time with the facets spread over the 64 lanes of the wave
+    const double* __restrict__ eq = hull + HULL_HDR;
+#pragma unroll 1
+    for (int u = 0; u < PP; ++u) {
+        const int64_t q = q0 + (int64_t)u * BLOCK;
+        const bool bl = ((border >> u) & 1u) && q < Q;
+        bool in = (inbits >> u) & 1u;
+        unsigned long long todo = __ballot(bl);
+        if (todo) {
+            double X = 0.0, Y = 0.0, Z = 0.0;
+            if (bl) geodetic2ecef(lat[q], lon[q], alt[q], X, Y, Z);
+            while (todo) {
+                const int src = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const double xs = __shfl(X, src), ys = __shfl(Y, src), zs = __shfl(Z, src);
+                bool viol = false;
+                for (int g = lane; g < F; g += 64) {
+                    const double d = fma(eq[4 * g], xs, fma(eq[4 * g + 1], ys, fma(eq[4 * g + 2], zs, eq[4 * g + 3])));
+                    viol = viol || !(d <= tol);
+                }
+                const bool any = __any(viol);
+                if (lane == src) in = !any;
+            }
+        }
+        if (q < Q) mask[q] = in ? 1 : 0;
+    }
+}
+
+// hullbuf <- [c0, s, offmax][eq][float4 facets][fp16 operand tiles]; c0 = foot of the origin's perpendicular on facet 0 (a
+// point of the hull surface), s = max(1, longest normal), offmax = max |n . c0 + d| / s (inf: a non-finite entry in the list or
+// an offset beyond the fp16 range - every point then takes the fp64 test).  Every block forms s and offmax itself.
+inline size_t hull_buf_bytes(size_t F)
+{
+    const size_t Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD, T = (F + 31) / 32;
+    return (HULL_HDR + 4 * F) * sizeof(double) + (Fp + 4) * sizeof(float4) + T * 64 * 16 + 64;
+}
+
+constexpr int HULL_PREP_BLOCKS = 4;
+__device__ __forceinline__ void prep_hull_body(int F, const double* __restrict__ eq, double* __restrict__ hullbuf, int bid, int nb)
 {
     const double c0x = -eq[3] * eq[0], c0y = -eq[3] * eq[1], c0z = -eq[3] * eq[2];
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        hullbuf[0] = c0x; hullbuf[1] = c0y; hullbuf[2] = c0z; hullbuf[3] = 0.0;
+    __shared__ double sh_n[256], sh_o[256];
+    double nm = 0.0, om = 0.0;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const double nx = eq[4 * f], ny = eq[4 * f + 1], nz = eq[4 * f + 2], off = nx * c0x + ny * c0y + nz * c0z + eq[4 * f + 3];
+        const double n2 = nx * nx + ny * ny + nz * nz;
+        nm = !(n2 <= 1.0e300) ? __builtin_inf() : fmax(nm, n2);
+        om = !(fabs(off) <= 1.0e300) ? __builtin_inf() : fmax(om, fabs(off));
     }
-    float4* pl = reinterpret_cast<float4*>(hullbuf + 4 + 4 * (size_t)F);
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+    sh_n[threadIdx.x] = nm;
+    sh_o[threadIdx.x] = om;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh_n[threadIdx.x] = fmax(sh_n[threadIdx.x], sh_n[threadIdx.x + w]);
+            sh_o[threadIdx.x] = fmax(sh_o[threadIdx.x], sh_o[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    const double s = fmax(1.0, sqrt(sh_n[0]));
+    double offmax = sh_o[0] / s;
+    if (!(s <= 1.0e150) || !(offmax <= 65000.0 * HULL_UNIT)) offmax = __builtin_inf();
+    if (threadIdx.x == 0 && bid == 0) {
+        hullbuf[0] = c0x; hullbuf[1] = c0y; hullbuf[2] = c0z; hullbuf[3] = s;
+        hullbuf[4] = offmax; hullbuf[5] = 0.0; hullbuf[6] = 0.0; hullbuf[7] = 0.0;
+    }
+    float4* pl = reinterpret_cast<float4*>(hullbuf + HULL_HDR + 4 * (size_t)F);
+    for (int f = bid * blockDim.x + threadIdx.x; f < F; f += nb * blockDim.x) {
         const double nx = eq[4 * f], ny = eq[4 * f + 1], nz = eq[4 * f + 2], off = eq[4 * f + 3];
-        hullbuf[4 + 4 * f] = nx; hullbuf[4 + 4 * f + 1] = ny; hullbuf[4 + 4 * f + 2] = nz; hullbuf[4 + 4 * f + 3] = off;
+        double* e = hullbuf + HULL_HDR + 4 * (size_t)f;
+        e[0] = nx; e[1] = ny; e[2] = nz; e[3] = off;
         pl[f] = make_float4((float)nx, (float)ny, (float)nz, (float)(nx * c0x + ny * c0y + nz * c0z + off));
     }
     // padding of the fp32 list (k_hull_mask reads it in groups of HULL_PAD): facet 0 again - the maximum does not change
     const int Fp = (F + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
-    for (int f = F + blockIdx.x * blockDim.x + threadIdx.x; f < Fp + 4; f += gridDim.x * blockDim.x)      // + the spare group
+    for (int f = F + bid * blockDim.x + threadIdx.x; f < Fp + 4; f += nb * blockDim.x)      // + the spare group
         pl[f] = make_float4((float)eq[0], (float)eq[1], (float)eq[2], (float)(eq[0] * c0x + eq[1] * c0y + eq[2] * c0z + eq[3]));
+    // the fp16 operand tiles of k_hull_mask_mx: tile t, lane l = facet 32 t + (l & 31) (facet 0 again past the end), k-slots
+    // 8 (l >> 5) ... + 7 of the table above its kernel
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4* tiles = reinterpret_cast<u4*>(pl + Fp + 4);
+    const int T = (F + 31) / 32;
+    const bool usable = offmax < __builtin_inf();
+    for (int i = bid * blockDim.x + threadIdx.x; i < T * 64; i += nb * blockDim.x) {
+        int f = 32 * (i >> 6) + (i & 31);
+        if (f >= F) f = 0;
+        const double nx = eq[4 * f], ny = eq[4 * f + 1], nz = eq[4 * f + 2];
+        const double off = nx * c0x + ny * c0y + nz * c0z + eq[4 * f + 3];
+        u4 v = {0u, 0u, 0u, 0u};
+        if (usable) {
+            const unsigned sx = hull_split((float)(nx / s * HULL_NSCALE)), sy = hull_split((float)(ny / s * HULL_NSCALE)),
+                           sz = hull_split((float)(nz / s * HULL_NSCALE)), so = hull_split((float)(off / s / HULL_UNIT));
+            if (((i >> 5) & 1) == 0) {
+                v[0] = (sx & 0xffffu) | (sy << 16);                  // (nxh, nyh)
+                v[1] = (sz & 0xffffu) | (sx & 0xffff0000u);          // (nzh, nxl)
+                v[2] = (sy >> 16) | (sz & 0xffff0000u);              // (nyl, nzl)
+                v[3] = v[0];                                         // (nxh, nyh)
+            } else {
+                v[0] = (sz & 0xffffu) | (sx & 0xffff0000u);          // (nzh, nxl)
+                v[1] = (sy >> 16) | (sz & 0xffff0000u);              // (nyl, nzl)
+                v[2] = so;                                           // (offh, offl)
+                v[3] = 0u;
+            }
+        }
+        tiles[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prep_hull(int F, const double* __restrict__ eq, double* __restrict__ hullbuf)
+{
+    prep_hull_body(F, eq, hullbuf, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int LCAP, int KCAP, int TT>
@@ -623,15 +916,30 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sph_fast(SphDev M, int64_t Q, co
 }
 
 // Cp[t][r*maxk + k] = C[t][k*L2 + r] * scale[r]
-__global__ void k_prep_coef(int T, int maxk, int L2, const double* __restrict__ C, const double* __restrict__ scale,
-                            double* __restrict__ Cp)
+__device__ __forceinline__ void prep_coef_body(int T, int maxk, int L2, const double* __restrict__ C,
+                                               const double* __restrict__ scale, double* __restrict__ Cp, int64_t bid)
 {
     const int N = maxk * L2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = bid * blockDim.x + threadIdx.x;
     if (i >= (int64_t)T * N) return;
     const int t = (int)(i / N), n = (int)(i % N);
     const int r = n / maxk, k = n % maxk;
     Cp[i] = C[(int64_t)t * N + k * L2 + r] * scale[r];
+}
+
+__global__ void k_prep_coef(int T, int maxk, int L2, const double* __restrict__ C, const double* __restrict__ scale,
+                            double* __restrict__ Cp)
+{
+    prep_coef_body(T, maxk, L2, C, scale, Cp, (int64_t)blockIdx.x);
+}
+
+// the two preparations of a masked evaluation call in one launch: blocks 0-3 the hull buffer, the others the coefficients
+__global__ __launch_bounds__(256) void k_prep_hull_coef(int F, const double* __restrict__ eq, double* __restrict__ hullbuf, int T,
+                                                        int maxk, int L2, const double* __restrict__ C,
+                                                        const double* __restrict__ scale, double* __restrict__ Cp)
+{
+    if (blockIdx.x < HULL_PREP_BLOCKS) prep_hull_body(F, eq, hullbuf, (int)blockIdx.x, HULL_PREP_BLOCKS);
+    else prep_coef_body(T, maxk, L2, C, scale, Cp, (int64_t)blockIdx.x - HULL_PREP_BLOCKS);
 }
 
 __global__ void k_transform_sph(SphDev M, int64_t P, const double* __restrict__ lat, const double* __restrict__ lon,
@@ -786,7 +1094,7 @@ struct EvalTimer {
     vi_ctx* c;
     explicit EvalTimer(vi_ctx* ctx) : c(ctx)
     {
-        c->evk_valid = hipEventRecord(c->evk0, c->stream) == hipSuccess;
+        c->evk_valid = c->evk_enabled && hipEventRecord(c->evk0, c->stream) == hipSuccess;
     }
     ~EvalTimer()
     {
@@ -986,6 +1294,23 @@ __global__ void k_mask_basis(int64_t Q, int N, const unsigned char* __restrict__
 }
 }  // namespace
 
+namespace {
+// the hull pass of a call: on the matrix cores (k_hull_mask_mx) unless VINTERP_HULL=fp32 asks for the packed-fp32 loop
+void launch_hull_mask(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt, int F, double tol)
+{
+    static const bool fp32 = [] {
+        const char* e = getenv("VINTERP_HULL");
+        return e && strcmp(e, "fp32") == 0;
+    }();
+    if (fp32)
+        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), 0, m->ctx->stream, Q, d_lat, d_lon, d_alt,
+                           m->d_hull, F, tol, m->d_mask);
+    else
+        hipLaunchKernelGGL(k_hull_mask_mx<HULL_MX_PP>, dim3(nblocks(Q, BLOCK * HULL_MX_PP)), dim3(BLOCK), 0, m->ctx->stream, Q,
+                           d_lat, d_lon, d_alt, m->d_hull, F, tol, m->d_mask);
+}
+}  // namespace
+
 extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, const double* d_lon, const double* d_alt,
                                  const double* d_hull_eq, int32_t F, double hull_tol, double* d_Y)
 {
@@ -995,7 +1320,7 @@ extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, co
     if (Q == 0) return VI_OK;
     int rc = vi_basis_f64(m, Q, d_lat, d_lon, d_alt, d_Y, 1, Q);
     if (rc != VI_OK || F == 0) return rc;
-    const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + ((size_t)F + HULL_PAD + 4) * sizeof(float4) + 64;
+    const size_t need = hull_buf_bytes((size_t)F);
     if (need > m->hull_bytes) {
         VI_HIP(hipStreamSynchronize(m->ctx->stream));
         if (m->d_hull) VI_HIP(hipFree(m->d_hull));
@@ -1004,7 +1329,7 @@ extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, co
         VI_HIP(hipMalloc((void**)&m->d_hull, need));
         m->hull_bytes = need;
     }
-    hipLaunchKernelGGL(k_prep_hull, dim3(4), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
+    hipLaunchKernelGGL(k_prep_hull, dim3(HULL_PREP_BLOCKS), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
     VI_HIP(hipGetLastError());
     if ((size_t)Q > m->mask_bytes) {
         VI_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -1014,8 +1339,7 @@ extern "C" int vi_eval_basis_f64(vi_model* m, int64_t Q, const double* d_lat, co
         VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
         m->mask_bytes = (size_t)Q;
     }
-    hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), 0, m->ctx->stream, Q,
-                       d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
+    launch_hull_mask(m, Q, d_lat, d_lon, d_alt, (int)F, hull_tol);
     hipLaunchKernelGGL(k_mask_basis, dim3(nblocks(Q, 256)), dim3(256), 0, m->ctx->stream, Q, m->N, m->d_mask, d_Y);
     VI_HIP(hipGetLastError());
     return VI_OK;
@@ -1062,8 +1386,20 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
     if (Q == 0 || T == 0) return VI_OK;
     VI_HIP(hipSetDevice(m->ctx->device));
     const int N = m->N;
+    const bool sph = m->kind == VI_MODEL_SPHHARMLAG;
+    if (sph) {
+        const size_t need = (size_t)T * N * sizeof(double);
+        if (need > m->coef_bytes) {
+            if (m->d_coef) VI_HIP(hipFree(m->d_coef));
+            m->d_coef = nullptr;
+            m->coef_bytes = 0;
+            VI_HIP(hipMalloc((void**)&m->d_coef, need));
+            m->coef_bytes = need;
+        }
+    }
+    const int L2 = sph ? m->sph.maxl * m->sph.maxl : 0;
     if (F > 0) {
-        const size_t need = (size_t)(4 + 4 * (size_t)F) * sizeof(double) + ((size_t)F + HULL_PAD + 4) * sizeof(float4) + 64;
+        const size_t need = hull_buf_bytes((size_t)F);
         if (need > m->hull_bytes) {
             VI_HIP(hipStreamSynchronize(m->ctx->stream));
             if (m->d_hull) VI_HIP(hipFree(m->d_hull));
@@ -1072,7 +1408,11 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
             VI_HIP(hipMalloc((void**)&m->d_hull, need));
             m->hull_bytes = need;
         }
-        hipLaunchKernelGGL(k_prep_hull, dim3(4), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
+        if (sph)            // the hull buffer and the coefficients of the call in one launch
+            hipLaunchKernelGGL(k_prep_hull_coef, dim3(HULL_PREP_BLOCKS + nblocks((int64_t)T * N, 256)), dim3(256), 0, m->ctx->stream,
+                               (int)F, d_hull_eq, m->d_hull, (int)T, m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
+        else
+            hipLaunchKernelGGL(k_prep_hull, dim3(HULL_PREP_BLOCKS), dim3(256), 0, m->ctx->stream, (int)F, d_hull_eq, m->d_hull);
         VI_HIP(hipGetLastError());
         if ((size_t)Q > m->mask_bytes) {
             VI_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -1082,24 +1422,16 @@ extern "C" int vi_eval_f64(vi_model* m, int64_t Q, const double* d_lat, const do
             VI_HIP(hipMalloc((void**)&m->d_mask, (size_t)Q));
             m->mask_bytes = (size_t)Q;
         }
-        hipLaunchKernelGGL(k_hull_mask, dim3(nblocks(Q, BLOCK * HULL_PP)), dim3(BLOCK), 0, m->ctx->stream, Q,
-                           d_lat, d_lon, d_alt, m->d_hull, (int)F, hull_tol, m->d_mask);
+        launch_hull_mask(m, Q, d_lat, d_lon, d_alt, (int)F, hull_tol);
         VI_HIP(hipGetLastError());
     }
     const unsigned char* d_mask = F > 0 ? m->d_mask : nullptr;
-    if (m->kind == VI_MODEL_SPHHARMLAG) {
-        const size_t need = (size_t)T * N * sizeof(double);
-        if (need > m->coef_bytes) {
-            if (m->d_coef) VI_HIP(hipFree(m->d_coef));
-            m->d_coef = nullptr;
-            m->coef_bytes = 0;
-            VI_HIP(hipMalloc((void**)&m->d_coef, need));
-            m->coef_bytes = need;
+    if (sph) {
+        if (F == 0) {
+            hipLaunchKernelGGL(k_prep_coef, dim3(nblocks((int64_t)T * N, 256)), dim3(256), 0, m->ctx->stream, (int)T,
+                               m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
+            VI_HIP(hipGetLastError());
         }
-        const int L2 = m->sph.maxl * m->sph.maxl;
-        hipLaunchKernelGGL(k_prep_coef, dim3(nblocks((int64_t)T * N, 256)), dim3(256), 0, m->ctx->stream, (int)T,
-                           m->sph.maxk, L2, d_C, m->sph.scale, m->d_coef);
-        VI_HIP(hipGetLastError());
         const int L = m->sph.maxl, K = m->sph.maxk;
         EvalTimer timer(m->ctx);
         // whole tiles of 16 timesteps go to the matrix-core kernel (vi_eval_mfma.hip); the rest to the VALU kernels

@@ -45,6 +45,7 @@ struct vi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk0 = nullptr, evk1 = nullptr;   // around the dominant kernel of the last vi_eval_f64 call
     bool evk_valid = false;
+    bool evk_enabled = false;                    // vi_ctx_set_eval_timing: the event pair costs ~7 us per call
     // grow-only device workspace for the fit entry points
     void* ws = nullptr;
     size_t ws_bytes = 0;
