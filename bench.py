@@ -575,7 +575,7 @@ def run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, 
                          'flops_model': '10 N^3 per solve (SURVEY 8d F2)'}}
         # ---- second object: the fused evaluation kernel (0.5 % of the step, the headline kernel of the evaluate half)
         out['roofline_eval'] = {
-            'kernel': 'k_eval_sph_fast<6,4,1> (+ k_hull_mask)', 'bound': 'fp64 VALU (AI ~94 flop/B >> 9.8)',
+            'kernel': 'k_eval_sph_fast<6,4,1> (+ k_hull_mask_mx)', 'bound': 'fp64 VALU (AI ~94 flop/B >> 9.8)',
             'kernel_ms_hull_on': ev_kernel_hull, 'kernel_ms_hull_off': ev_kernel_nohull, 'call_ms_hull_off': ev_call_nohull,
             'call_ms_hull_on': ev,
             'hbm': {'achieved': EVAL_BYTES_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
@@ -585,7 +585,7 @@ def run_c1(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world, 
                      'unit': 'TFLOP/s', 'frac': EVAL_FLOPS_PER_POINT * Q * T / (ev_kernel_nohull * 1e-3) / 1e12 / FP64_PEAK_TF,
                      'flops_model': '~3.0 kflop/point at the default order (SURVEY 8d E1)'},
             'points_per_sec_hull_on': Q * T / (ev * 1e-3), 'points_per_sec_hull_off': Q * T / (ev_kernel_nohull * 1e-3),
-            'hull_note': 'hull on: the whole vi_eval_f64 call (mask pass k_hull_mask + evaluation kernel, HIP events around '
+            'hull_note': 'hull on: the whole vi_eval_f64 call (matrix-core mask pass k_hull_mask_mx + evaluation kernel, HIP events around '
                          'the call); hull off: the evaluation kernel alone'}
         if many is not None:
             out['eval_many_timesteps'] = many
