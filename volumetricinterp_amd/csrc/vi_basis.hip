@@ -435,37 +435,13 @@ __device__ __forceinline__ unsigned hull_split(float v)          // (hi, lo) hal
     return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 
-// sin and cos for the prefilter's geodetic -> ECEF: Cody-Waite reduction by pi/2 in two pieces (exact for |x| < 1e4: k has 13
-// bits) and the two kernels of fdlibm on |r| <= pi/4; 2.2e-16 absolute against libm on 2e7 arguments (a third of the
-// instructions of the library's sincos, which carries the Payne-Hanek path for huge arguments).  Only the prefilter uses it - the
-// points within the band are decided from the library's values, like the evaluation kernels' geometry.
-__device__ __forceinline__ void hull_sincos(double x, double& sn, double& cs)
-{
-    const double k = rint(x * 0.63661977236758134308);
-    double r = fma(-k, 1.57079632679489655800e+00, x);
-    r = fma(-k, 6.12323399573676603587e-17, r);
-    const double z = r * r;
-    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                                 8.33333333332248946124e-03), -1.66666666666666324348e-01);
-    const double sr = fma(r * z, ps, r);
-    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const int q = (int)k & 3;
-    const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
-    sn = (q & 2) ? -a : a;
-    cs = ((q + 1) & 2) ? -b : b;
-}
-
-// geodetic2ecef (vi_sph_device.h) with hull_sincos; false when an angle is outside the range of its reduction (or NaN)
+// geodetic2ecef with sincos_cw (vi_sph_device.h); false when an angle is outside the range of its reduction (or NaN)
 __device__ __forceinline__ bool hull_geodetic2ecef(double lat, double lon, double alt, double& X, double& Y, double& Z)
 {
     const double la = lat * DEG2RAD, lo = lon * DEG2RAD;
     double sl, cl, so, co;
-    hull_sincos(la, sl, cl);
-    hull_sincos(lo, so, co);
+    sincos_cw(la, sl, cl);
+    sincos_cw(lo, so, co);
     const double a2 = WGS84_A * WGS84_A, b2 = WGS84_B * WGS84_B;
     const double Nn = a2 / sqrt(a2 * cl * cl + b2 * sl * sl);
     const double ba = WGS84_B / WGS84_A;
@@ -503,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_hull_mask_mx(int64_t Q, const doub
     const float offmax = (float)hull[4];                                         // max |n . c0 + d| / s; inf: no prefilter
     // geodetic -> ECEF of the thread's PP points, unrolled: their 3 PP loads are in flight together (one after the other a
     // wave waited out a memory latency per point: the pass reads 24 B a point, 50 MB for 128^3).  thr < 0 marks a point the
-    // prefilter does not judge (non-finite, far away, angle beyond the range of hull_sincos).
+    // prefilter does not judge (non-finite, far away, angle beyond the range of sincos_cw).
     // The B operands: lanes 0-31 hold k 0-7 of their column, lanes 32-63 k 8-15; one swap of the upper half of one register
     // with the lower half of another makes a register of each of the two groups a 64-lane set of points consists of.
     unsigned Bf[2 * PP][4];
