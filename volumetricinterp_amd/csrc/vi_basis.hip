@@ -536,21 +536,25 @@ __global__ __launch_bounds__(BLOCK, 4) void k_hull_mask_mx(int64_t Q, const doub
         // compiler the loop is product -> wait -> eight maxima -> next product on ONE accumulator, 85 cycles per product
         // and SIMD at four waves against 53 this way (tools/microbench/mfma_max3_overlap.hip).  The products are inline
         // assembly, so the wait between a matrix-core write and a vector read of it is ours to keep: s_nop 15 (16 wait
-        // states; the 8-pass product needs 12) tied to the accumulator in front of its first use.
+        // states; the 8-pass product needs 12) inside the same statement, so that nothing the compiler may place behind
+        // it - the maxima, a copy - reads the accumulator early; "=&v": the result does not share registers with A or B.
         f16v pa, pb;
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(pa) : "v"(A), "v"((u4){Bf[0][0], Bf[0][1], Bf[0][2], Bf[0][3]}));
+        // (`held`: the other accumulator, named as an operand so that its maxima stay behind this product - the compiler is
+        // otherwise free to take them first and to put both accumulators into the same registers)
+#define VI_HULL_MFMA(acc, g, held)                                                                                        \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\ts_nop 15"                                                      \
+                 : "=&v"(acc), "+v"(held)                                                                                 \
+                 : "v"(A), "v"((u4){Bf[g][0], Bf[g][1], Bf[g][2], Bf[g][3]}))
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\ts_nop 15"
+                     : "=&v"(pa) : "v"(A), "v"((u4){Bf[0][0], Bf[0][1], Bf[0][2], Bf[0][3]}));
 #pragma unroll
         for (int g = 0; g < 2 * PP; g += 2) {
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
-                         : "=v"(pb) : "v"(A), "v"((u4){Bf[g + 1][0], Bf[g + 1][1], Bf[g + 1][2], Bf[g + 1][3]}));
-            asm volatile("s_nop 15" : "+v"(pa));
+            VI_HULL_MFMA(pb, g + 1, pa);
             dmax[g] = hull_max16(pa, dmax[g]);
-            if (g + 2 < 2 * PP)
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
-                             : "=v"(pa) : "v"(A), "v"((u4){Bf[g + 2][0], Bf[g + 2][1], Bf[g + 2][2], Bf[g + 2][3]}));
-            asm volatile("s_nop 15" : "+v"(pb));
+            if (g + 2 < 2 * PP) VI_HULL_MFMA(pa, g + 2, pb);
             dmax[g + 1] = hull_max16(pb, dmax[g + 1]);
         }
+#undef VI_HULL_MFMA
         if ((t & (t + 1)) == 0 && t + 1 < T) {
             // after tiles 0, 1, 3, 7, ...: a point is outside as soon as ONE facet says so - leave when every point of the
             // wave is decided (the host hands the facets over in greedy-cover order: the first tile decides 98 % of them)
