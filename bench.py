@@ -719,9 +719,12 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
         ach = lds_bytes_step / busy_s / 1e9
         fit_roof = {
             'kernel': 'K3: k_jacobi_solve launches + the Jacobi rounds inside k_brent_warm (in-LDS eigen-solves of the fit)',
-            'bound': 'lds', 'achieved': ach, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / LDS_PEAK_GBS, 'traffic': None,
-            'traffic_note': 'HBM traffic is not the resource: per system 166 KB in, ~1.3 MB of rotation log out and back, '
-                            'against ~0.1-0.5 GB through LDS',
+            'bound': 'lds', 'achieved': ach, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / LDS_PEAK_GBS,
+            'traffic': 8.22e11 * (share / 10000.) if N == 144 else None,
+            'traffic_note': 'HBM bytes of the K3 kernels (k_jacobi_solve_v2 + k_brent_warm) per step of 10 000 records from the '
+                            'committed PMC passes (profiles/r4_k3_hbm_pmc.txt: FETCH_SIZE as reported + WRITE_SIZE; 1.26e12 with '
+                            'every read doubled), scaled by the records of this rank: 0.4-0.6 TB/s, 4-6 % of the bytes through '
+                            'LDS - HBM is not the resource',
             'definition': 'algorithmic LDS bytes of all K3 rounds of a step / the time K3 kernels were running in that step = '
                           'min(sum of the launch durations over the %d concurrent pipelines, wall time of the fit)' % pipelines,
             'lds_bytes_per_step': lds_bytes_step, 'rounds_per_step': rounds_step, 'systems_per_step': st['systems'] / args.steps,
