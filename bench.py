@@ -639,12 +639,15 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     dC = ctx.empty((max(1, share), N))
     dout = ctx.empty((TILE, Q))                            # one tile of densities, overwritten tile after tile (the consumer's buffer)
     dY = ctx.empty((N, Q)) if resident else None           # the basis matrix of the grid: 19 GB of the GPU's 288
+    # the fit's results (coefficients, covariances: 8 N^2 bytes per record, 1.66 GB per 10 000) land in the same page-locked arrays
+    # step after step - a consumer that writes a shard out before it fits the next one does the same
+    res_bufs = eng.result_buffers(calccov=True) if share else None
     fit_s, eval_ms, basis_ms, step_s_list, outcomes = [], [], [], [], None
 
     def step(record=False):
         nonlocal outcomes
         t0 = time.perf_counter()
-        res = eng.fit_resident([P] * share, calccov=True) if share else None
+        res = eng.fit_resident([P] * share, calccov=True, out=res_bufs) if share else None
         t1 = time.perf_counter()
         ems = bms = 0.
         if share:

@@ -660,3 +660,47 @@ def test_c4_fp32_chain_sweep(capsys, maxk, maxl, cap):
               '128^3 points in %.3f ms (fp64 %.3f ms): x%.2f'
               % (maxk, maxl, N, err, worst, 'within' if err <= 1e-6 else 'MISSES it', t32, t64, t64 / t32))
     assert err <= 1e-4
+
+
+def test_fit_into_the_callers_result_arrays():
+    """fit_resident(out=result_buffers()): the same numbers as the fit that allocates its own arrays, bit for bit, written into
+    the caller's (page-locked) arrays - for a batch in one chain and for one split over two pipelines; a second fit reuses them;
+    arrays of the wrong shape or type are refused."""
+    from volumetricinterp_amd import synth
+    from volumetricinterp_amd.fitengine import FitEngine
+    from volumetricinterp_amd.models.sphharmlag import Model
+    m = Model(io.StringIO(CFG144))
+    ctx = m.ctx
+    lat, lon, alt = synth.beams(*synth.GEOM_C2, seed=0)
+    P, N = lat.size, m.nbasis
+    d = [ctx.to_device(a) for a in (lat, lon, alt)]
+    At = m.basis_device(d[0], d[1], d[2], P, transposed=True)
+    A = At.download().T
+    R = m.eval_reg_matricies['curvature']()
+    for T in (24, 160):
+        value, error = synth.synth_records(A, T, seed0=4242)
+        eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
+        eng.upload_records(error**-2., value)
+        ref = eng.fit_resident([P] * T, calccov=True)
+        assert (eng.stats.get('pipelines', 1) > 1) == (T == 160)
+        bufs = eng.result_buffers(calccov=True)
+        for rep in range(2):
+            for b in bufs:
+                b[...] = 0
+            got = eng.fit_resident([P] * T, calccov=True, out=bufs)
+            assert got['Coeffs'] is bufs[0] and got['Covariance'] is bufs[1] and got['chi_sq'] is bufs[2] and got['ranks'] is bufs[3]
+            for key in ('Coeffs', 'Covariance', 'chi_sq', 'ranks'):
+                assert np.array_equal(got[key], ref[key], equal_nan=True), (T, rep, key)
+            assert [p['curvature'] for p in got['reg_params']] == pytest.approx([p['curvature'] for p in ref['reg_params']],
+                                                                                rel=0, abs=0, nan_ok=True)
+        nocov = eng.fit_resident([P] * T, calccov=False, out=eng.result_buffers(calccov=False, pinned=False))
+        # (without covariances the coefficients come from the vector back-transformation, not from H y: same to 1e-6, not bitwise)
+        assert nocov['Covariance'] is None and np.array_equal(np.isnan(nocov['Coeffs']), np.isnan(ref['Coeffs']))
+        assert rel(np.nan_to_num(nocov['Coeffs']), np.nan_to_num(ref['Coeffs'])) <= 1e-6
+        with pytest.raises(ValueError):
+            eng.fit_resident([P] * T, out=(bufs[0], bufs[1][:, :, :N - 1], bufs[2], bufs[3]))
+        with pytest.raises(ValueError):
+            eng.fit_resident([P] * T, out=(bufs[0], bufs[1], bufs[2], bufs[3].astype(np.int64)))
+        eng.close()
+    for b in d:
+        b.free()
