@@ -141,7 +141,9 @@ int  vi_transform_f64(vi_model* model, int64_t P, const double* d_lat, const dou
  * out[t*Q + q] = sum_n basis_n(q) * C[t*N + n]; NaN where the point fails the convex-hull test
  * (estimate.py:119-121, :153-178) when hull_eq != NULL: a point is inside iff
  * max_f (hull_eq[f][0..2] . ecef(q) + hull_eq[f][3]) <= hull_tol.  The basis matrix is never
- * materialised. */
+ * materialised.  hull_eq is what scipy.spatial.ConvexHull(...).equations holds (unit normals, metres); the test is exact
+ * in fp64 for any list - a reduced-precision pass only sorts out the points further from the surface than its own error
+ * bound, which assumes nothing but scales with the longest normal (lists of much shorter normals run slower, not wrong). */
 int  vi_eval_f64(vi_model* model, int64_t Q, const double* d_lat, const double* d_lon,
                  const double* d_alt, int64_t T, const double* d_C,
                  const double* d_hull_eq, int32_t F, double hull_tol, double* d_out);
