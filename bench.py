@@ -5,7 +5,7 @@ ONE workload at every N (round 4; VERDICT round 3: the N = 1 and the N > 1 lines
 curve could be formed): **workload c3 = BASELINE.json configs[3]** - 10000 timesteps (26 beams x 100 ranges, default order
 MAXK=4 MAXL=6 -> N=144, curvature regularisation, chi^2 search, covariance) sharded ceil(T/N) per rank - independent records, no
 data-path collective -, each rank fits its shard as one batch and evaluates EVERY timestep of it on a 256^3 geodetic grid with
-the hull mask (basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call), all of it inside
+the hull mask (basis matrix of the grid resident in HBM, matrix-core product K2r over 512 timesteps per call), all of it inside
 the timed region.  A "step" is one such pass; strong scaling; value = timesteps/s = T / (barrier-to-barrier wall time per
 step, max over ranks).  The line carries
   roofline       the dominant part of the step, the FIT: the in-LDS eigen-solves K3 (k_jacobi_solve launches + the Jacobi rounds
@@ -59,6 +59,7 @@ EVAL_BYTES_PER_POINT = 32.0    # 3 x 8 B coordinates in + 8 B dens
 EVAL_FLOPS_PER_POINT = 3.0e3   # SURVEY 8d E1 estimate at the default order
 # K2r, one call of 256 timesteps on 256^3 points: HBM bytes read + written from the PMC passes of profiles/r3_k2r_pmc.txt
 K2R_PMC_BYTES_PER_256_TIMESTEPS = 30.2e9 + 34.4e9
+K2R_PMC_BYTES_PER_512_TIMESTEPS = 34.55e9 + 68.74e9          # same passes (profiles/r3_k2r_pmc.txt), 512 timesteps per call
 
 
 def parse_args():
@@ -626,7 +627,8 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
     lo, hi = shard_bounds(Ttot, rank, world)
     share = hi - lo
     resident = os.environ.get('VINTERP_C3_EVAL', 'resident') != 'fused'
-    TILE = min(256 if resident else 64, max(1, share))
+    # timesteps per evaluation call: 512 (K2r 64.0 TF against 61.6 at 256 and 57.7 at 128; the tile of densities is 69 GB of the 288)
+    TILE = min(512 if resident else 64, max(1, share))
     value, error = synth.synth_records(A, share, seed0=1000 + lo) if share else (np.zeros((0, P)), np.ones((0, P)))
     eng = FitEngine(ctx, At, P, N, {'curvature': R}, ['curvature'])
     eng.upload_records(error**-2., value)
@@ -745,7 +747,8 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
                      'flops_model': '12 flop per stored element and round, counted rounds (a converged cold solve of 10 sweeps is '
                                     '~30 N^3; SURVEY 8d F2 quotes ~10 N^3 per solve)'},
             'records_per_sec_fit': share / fit_wall}
-    k2r_traffic = K2R_PMC_BYTES_PER_256_TIMESTEPS if (resident and Q == 256**3 and TILE == 256) else None
+    k2r_traffic = ({256: K2R_PMC_BYTES_PER_256_TIMESTEPS, 512: K2R_PMC_BYTES_PER_512_TIMESTEPS}.get(TILE)
+                   if (resident and Q == 256**3) else None)
     return {
         'metric': 'fit+eval timesteps/sec', 'value': Ttot / step_s, 'unit': 'timesteps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
@@ -753,7 +756,7 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
         'config': {'workload': 'configs[3]: %d timesteps (26-beam x 100-range records, N=144, curvature, chi2 search, '
                                'covariance) sharded ceil(T/N) per rank, no data-path collective; each rank fits its shard as '
                                'one batch and evaluates it on a 256^3 geodetic grid with the hull mask (%s), fp64'
-                               % (Ttot, 'basis matrix of the grid resident in HBM, matrix-core product K2r over 256 timesteps per call'
+                               % (Ttot, 'basis matrix of the grid resident in HBM, matrix-core product K2r over up to 512 timesteps per call'
                                   if resident else 'fused matrix-core kernel, basis recomputed per 32 timesteps'),
                    'timesteps': Ttot, 'timesteps_per_rank': -(-Ttot // world), 'grid_points': Q,
                    'evaluation': 'every timestep of the shard is evaluated on the grid inside the timed region, %d timesteps per '
@@ -779,8 +782,9 @@ def run_c3(args, ctx, comm, model, h, At, A, R, hull_eq, hull_tol, rank, world):
             'ms_per_step': float(np.mean(eval_ms)) if eval_ms else None,
             'share_of_step': (float(np.mean(eval_ms)) * 1e-3 / step_s) if eval_ms else None,
             'flops_model': '2 N flop per point-timestep (SURVEY 8d E2)', 'traffic': k2r_traffic,
-            'traffic_note': 'HBM bytes per call of 256 timesteps on 256^3 points from the committed PMC passes '
-                            '(profiles/r3_k2r_pmc.txt: read + written), algorithmic 53.7 GB'},
+            'traffic_note': 'HBM bytes per call of %d timesteps on 256^3 points from the committed PMC passes '
+                            '(profiles/r3_k2r_pmc.txt: read + written), algorithmic %.1f GB'
+                            % (TILE, (N * Q * 8 + TILE * Q * 8) / 1e9)},
         'comm': {'backend': comm.backend, 'rccl_broadcast': bool(comm.rccl_ready), 'notes': comm.notes},
     }
 
